@@ -1,0 +1,194 @@
+/*
+ * mzhip.h -- C ABI of libmzhip.so, the MI355X (gfx950) MuZero self-play hot path.
+ *
+ * Drop-in boundary for the reference's MCTS self-play path (fidel-schaposnik/muzero):
+ *   MCTSAgent.run_mcts  and everything it calls            reference agent.py:154-232
+ *   MinMaxStats / KnownBounds                               reference utils.py:37-76
+ *   MuZeroConfig.exploration_function                       reference config.py:159-160
+ *   Network.initial_inference / recurrent_inference         reference network.py:209-254
+ *   BatchNetworkOutput.split_batch / to_scalar              reference network.py:165-174, config.py:25-40
+ *
+ * Conventions
+ *   - plain C types only; every array argument is a DEVICE pointer unless it says "host";
+ *   - all work is enqueued on the HIP stream the pool / net was created with (or set_stream); calls
+ *     return after enqueueing unless they say "synchronises";
+ *   - every function returns MZ_OK (0) or a negative mz_status; mz_last_error() gives the message of the
+ *     last failure on the calling thread; nothing throws across this boundary;
+ *   - a pool is driven by one host thread at a time (the reference agent is single-threaded);
+ *   - T = trees (concurrent games), A = action_space_size, N = num_simulations.
+ *
+ * Tree layout: every expanded node owns a "block" of A child slots.  Block 0 is the root; the leaf expanded
+ * by simulation s (0-based) becomes block s+1 in EVERY tree (the search runs in lockstep), so a
+ * hidden-state tensor shaped [N+1][T][H] is addressed by (block, tree) with no per-tree allocator.
+ */
+#ifndef MZHIP_H
+#define MZHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZHIP_VERSION 1
+
+typedef enum mz_status {
+    MZ_OK = 0,
+    MZ_ERR_INVALID_ARG = -1,
+    MZ_ERR_OOM = -2,
+    MZ_ERR_HIP = -3,
+    MZ_ERR_STATE = -4,      /* call sequence violated, e.g. more simulations than max_simulations */
+    MZ_ERR_NO_DEVICE = -5
+} mz_status;
+
+typedef struct mz_pool mz_pool_t;
+typedef struct mz_net mz_net_t;
+
+/* Search configuration: MCTSConfig + GameConfig + value KnownBounds (reference config.py:43-53,91-102). */
+typedef struct mz_pool_config {
+    int32_t num_trees;         /* T >= 1 */
+    int32_t num_actions;       /* A in [1, 4096] */
+    int32_t max_simulations;   /* N >= 1; the pool holds N+1 blocks per tree */
+    int32_t num_players;       /* 1 or 2; 2 negates the discount (agent.py:150-152) */
+    int32_t has_known_bounds;  /* 0: live MinMaxStats (utils.py:63-66); 1: use known_min/known_max */
+    int32_t reserved;
+    double discount;           /* GameConfig.discount */
+    double default_value;      /* MCTSConfig.default_value: exploitation score of unvisited children */
+    double known_min;          /* KnownBounds.endpoints() (utils.py:45-49) */
+    double known_max;
+    const double* log_table;   /* host, N+2 entries, log_table[n] = 2*log(n+1) (config.py:159-160);
+                                  NULL: the library tabulates it with the host libm */
+} mz_pool_config_t;
+
+const char* mz_last_error(void);
+int mz_version(void);
+/* Number of visible HIP devices (0 when there is none); never initialises a device context. */
+int mz_device_count(void);
+
+/* ---- tree pool ------------------------------------------------------------------------------------ */
+
+/* Allocates the SoA tree pool on the current HIP device. stream: a hipStream_t (NULL = default stream). */
+int mz_pool_create(const mz_pool_config_t* config, void* stream, mz_pool_t** out_pool);
+int mz_pool_destroy(mz_pool_t* pool);
+int mz_pool_set_stream(mz_pool_t* pool, void* stream);
+
+/* New root + MinMaxStats for every tree, no tree reuse (MCTSAgent.make_move, agent.py:220-221). */
+int mz_pool_reset(mz_pool_t* pool);
+
+/* MCTSAgent.expand_node on the roots (agent.py:154-160,223-225).
+ *   priors  [T,A] f32: NetworkOutput.masked_policy(legal) as the reference computes it -- FULL length A,
+ *           zero at illegal actions.  Root child k (action legal[t,k]) receives priors[t,k]: the
+ *           reference zips the legal list with the full-length policy, i.e. positionally.
+ *   legal   [T,A] i32: legal actions of tree t in legal[t, 0..n_legal[t]); NULL = every action legal.
+ *   n_legal [T]   i32: NULL = A.  n_legal[t] == 0 marks tree t inactive: every later call skips it and
+ *           reports parent = action = -1 (the reference would raise on an un-expandable root). */
+int mz_expand_roots(mz_pool_t* pool, const float* priors, const int32_t* legal, const int32_t* n_legal);
+/* Same, computing masked_policy on the device from raw logits [T,A] f32 (network.py:142-146: exp(logit),
+ * mask, NumPy-pairwise fp32 sum, IEEE divide, no max-subtraction).  expf differs from NumPy's SIMD exp
+ * by <= 2 ulp, so this entry is tolerance-tested, not bit-exact. */
+int mz_expand_roots_logits(mz_pool_t* pool, const float* logits, const int32_t* legal, const int32_t* n_legal);
+
+/* MCTSAgent.add_exploration_noise (agent.py:170-175): prior = prior*(1-frac) + noise*frac in fp64.
+ *   noise [T,A] f64: Dirichlet draw of tree t in noise[t, 0..n_legal[t]) (injected: the reference draws it
+ *   with np.random.dirichlet on the host). */
+int mz_add_root_noise(mz_pool_t* pool, const double* noise, double frac);
+
+/* MCTSAgent.select_leaf for every tree (agent.py:177-190), one sub-wave group per tree.
+ *   out_parent_block [T] i32: block of leaf.parent -- the row of the [N+1][T][H] hidden tensor to feed
+ *                             recurrent_inference with (agent.py:204);
+ *   out_action       [T] i32: the last action on the path (agent.py:205).
+ * The selection path is kept in the pool for the following mz_expand_backprop. */
+int mz_select(mz_pool_t* pool, int32_t* out_parent_block, int32_t* out_action);
+
+/* expand_node(leaf, all actions) + backpropagate(leaf, value) (agent.py:208-211, 192-196) for the leaf of
+ * the last mz_select.  priors [T,A] f32 (masked_policy over all A actions), reward [T] f32, value [T] f32
+ * are the already-scalarised network outputs (split_batch, network.py:165-174).  The new node becomes
+ * block (number of simulations done so far + 1) in every tree. */
+int mz_expand_backprop(mz_pool_t* pool, const float* priors, const float* reward, const float* value);
+int mz_expand_backprop_logits(mz_pool_t* pool, const float* logits, const float* reward, const float* value);
+
+/* mz_expand_backprop immediately followed by the next mz_select in ONE launch (halves the tree launches
+ * of run_mcts; results are identical to the two separate calls). */
+int mz_step(mz_pool_t* pool, const float* priors, const float* reward, const float* value,
+            int32_t* out_parent_block, int32_t* out_action);
+int mz_step_logits(mz_pool_t* pool, const float* logits, const float* reward, const float* value,
+                   int32_t* out_parent_block, int32_t* out_action);
+
+/* Search statistics of the roots (MCTSAgent.make_move, agent.py:229-231). Any output may be NULL.
+ *   visits     [T,A] i32: visit count of the root child for each ACTION (0 where illegal);
+ *   root_value [T]   f64: root.value = value_sum / visit_count (nan before the first simulation);
+ *   minmax     [T,2] f64: MinMaxStats.minimum, .maximum (+inf, -inf while untouched / with known bounds);
+ *   policy     [T,A] f32: visits / root visit count, computed in fp64 and rounded to fp32 like
+ *                         tf.constant(python floats). */
+int mz_root_stats(mz_pool_t* pool, int32_t* visits, double* root_value, double* minmax, float* policy);
+
+/* MCTSAgent.select_action / softmax_sample (agent.py:162-168,213-217).
+ *   u           [T] f64: the uniform draw random.random() that random.choices would consume (injected);
+ *   temperature [T] f64: visit_softmax_temperature_fn per tree (config.py:153-157); 0 = arg-max with ties
+ *                        to the largest action; otherwise weights count**(1/t), cumulative fp64 sums and
+ *                        bisect_right(cum, u*total, 0, n-1) like CPython's random.choices.
+ *   out_action  [T] i32. */
+int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature, int32_t* out_action);
+
+/* Measurement counters, host output, synchronises the stream.
+ *   out[0] simulations backed up (summed over trees), out[1] sum over those simulations of d = number of
+ *   expanded nodes on the selection path (root included), out[2] select launches, out[3] backprop launches. */
+int mz_pool_counters(mz_pool_t* pool, int64_t* out4_host);
+
+/* Inspection (Node views, tests): copies one block of one tree to HOST arrays of A entries each
+ * (any may be NULL); synchronises.  block 0 = root (its priors are the fp64 noise-mixed ones).
+ *   actions i32, count i32, value_sum f64, prior f64, reward f32 (valid where count>0), child i32 (block
+ *   of the child where count>0, else -1).  *out_num_children receives the number of valid entries. */
+int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* out_num_children,
+                       int32_t* actions, int32_t* count, double* value_sum, double* prior, float* reward,
+                       int32_t* child);
+/* Number of blocks currently in use per tree (= simulations done + 1 after mz_expand_roots, else 0). */
+int mz_pool_num_blocks(mz_pool_t* pool);
+/* Device bytes held by the pool. */
+int64_t mz_pool_bytes(mz_pool_t* pool);
+
+/* ---- networks (Network.initial_inference / recurrent_inference, reference network.py:209-254) ------- */
+
+typedef enum mz_net_kind {
+    MZ_NET_TICTACTOE = 1,   /* reference games/tictactoe.py:151-220 */
+    MZ_NET_CARTPOLE = 2     /* reference games/cartpole.py:63-139  */
+} mz_net_kind;
+
+/* Number of f32 weights the flat weight buffer of a network kind holds (layout: DESIGN.md "weights"). */
+int64_t mz_net_num_weights(int32_t kind);
+/* Hidden-state floats per game for a network kind (TicTacToe 3*3*128, CartPole 128). */
+int32_t mz_net_hidden_size(int32_t kind);
+
+/* Uploads (and re-lays-out for the kernels) a flat f32 weight buffer in Keras order.
+ *   weights_host: HOST pointer, mz_net_num_weights(kind) floats;  training_steps: Network.training_steps(). */
+int mz_net_create(int32_t kind, const float* weights_host, int64_t num_weights, int64_t training_steps,
+                  void* stream, mz_net_t** out_net);
+int mz_net_destroy(mz_net_t* net);
+int mz_net_set_stream(mz_net_t* net, void* stream);
+int64_t mz_net_training_steps(mz_net_t* net);
+
+/* Network.initial_inference (network.py:221-229) fused with split_batch's to_scalar (network.py:165-174).
+ *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4);
+ *   out_hidden  [B, H] f32;  out_value [B] f32 (scalar: identity or support_to_scalar, utils.py:146-148);
+ *   out_logits  [B, A] f32;  out_value_raw: NULL or the un-scalarised head ([B,1] or [B,101]). */
+int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden,
+                     float* out_value, float* out_logits, float* out_value_raw);
+
+/* Network.recurrent_inference (network.py:246-254) fused with the state-action encoder
+ * (network.py:14-40,88-104), the parent-hidden-state gather of run_mcts (agent.py:204) and to_scalar.
+ *   hidden_base f32, parent_block [B] i32 (NULL = all zero), block_stride (floats between consecutive
+ *       blocks): entry b reads its H input floats at hidden_base + parent_block[b]*block_stride + b*H.
+ *       Pass the [N+1][T][H] hidden tensor, mz_select's out_parent_block and block_stride = T*H to gather
+ *       leaf.parent.hidden_state in the kernel's operand load; pass NULL / 0 for a plain [B,H] batch.
+ *       A negative parent_block skips that entry (inactive tree): its outputs are left untouched;
+ *   action [B] i32 in [0, A);
+ *   out_hidden [B,H] (e.g. block s+1 of the hidden tensor); out_reward [B]; out_value [B] (scalarised);
+ *   out_logits [B,A]; out_value_raw: NULL or the un-scalarised value head ([B,1] or [B,101]). */
+int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                       int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                       float* out_value, float* out_logits, float* out_value_raw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZHIP_H */

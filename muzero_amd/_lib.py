@@ -1,0 +1,79 @@
+"""ctypes binding of libmzhip.so (include/mzhip.h).  There is NO CPU fallback: a missing library or a
+missing GPU raises, loudly."""
+import ctypes
+import os
+
+from .exceptions import MuZeroError, MuZeroHipError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmzhip.so')
+
+c_void_p, c_int32, c_int64, c_double = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+
+class PoolConfig(ctypes.Structure):
+    """mz_pool_config_t"""
+    _fields_ = [('num_trees', c_int32), ('num_actions', c_int32), ('max_simulations', c_int32),
+                ('num_players', c_int32), ('has_known_bounds', c_int32), ('reserved', c_int32),
+                ('discount', c_double), ('default_value', c_double), ('known_min', c_double),
+                ('known_max', c_double), ('log_table', c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/mzhip.h declares
+PROTOTYPES = {
+    'mz_last_error': (ctypes.c_char_p, []),
+    'mz_version': (ctypes.c_int, []),
+    'mz_device_count': (ctypes.c_int, []),
+    'mz_pool_create': (ctypes.c_int, [ctypes.POINTER(PoolConfig), c_void_p, ctypes.POINTER(c_void_p)]),
+    'mz_pool_destroy': (ctypes.c_int, [c_void_p]),
+    'mz_pool_set_stream': (ctypes.c_int, [c_void_p, c_void_p]),
+    'mz_pool_reset': (ctypes.c_int, [c_void_p]),
+    'mz_expand_roots': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_expand_roots_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_add_root_noise': (ctypes.c_int, [c_void_p, c_void_p, c_double]),
+    'mz_select': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    'mz_expand_backprop': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_expand_backprop_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_step': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_step_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_root_stats': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_select_action': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_pool_counters': (ctypes.c_int, [c_void_p, c_void_p]),
+    'mz_pool_read_block': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+    'mz_pool_num_blocks': (ctypes.c_int, [c_void_p]),
+    'mz_pool_bytes': (c_int64, [c_void_p]),
+    'mz_net_num_weights': (c_int64, [c_int32]),
+    'mz_net_hidden_size': (c_int32, [c_int32]),
+    'mz_net_create': (ctypes.c_int, [c_int32, c_void_p, c_int64, c_int64, c_void_p, ctypes.POINTER(c_void_p)]),
+    'mz_net_destroy': (ctypes.c_int, [c_void_p]),
+    'mz_net_set_stream': (ctypes.c_int, [c_void_p, c_void_p]),
+    'mz_net_training_steps': (c_int64, [c_void_p]),
+    'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_infer_recurrent': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmzhip.so and bind every prototype; raises MuZeroError if the build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MuZeroError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'(hipcc --offload-arch=gfx950). muzero_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status < 0:
+        raise MuZeroHipError(status, load().mz_last_error().decode('utf-8', 'replace'))

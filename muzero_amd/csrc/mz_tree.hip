@@ -1,0 +1,918 @@
+// GPU-resident SoA tree pool and the lockstep MCTS kernels (gfx950, wave64).
+//
+// What this replaces in the reference (fidel-schaposnik/muzero, file:line relative to /root/reference):
+//   Node                       agent.py:103-123   -> child slots of a per-node block in HBM
+//   MinMaxStats                utils.py:52-76     -> one (min,max) fp64 pair per tree
+//   expand_node/masked_policy  agent.py:154-160, network.py:142-146
+//   add_exploration_noise      agent.py:170-175
+//   select_leaf/child/ucb      agent.py:177-190
+//   backpropagate              agent.py:192-196
+//   run_mcts loop body         agent.py:198-211
+//   select_action/softmax      agent.py:162-168,213-217
+//
+// Layout.  Tree t owns N+1 records ("blocks") of RS bytes, block e at blocks + (t*(N+1)+e)*RS:
+//     value_sum f64[A] | visit_count i32[A] | prior f32[A] | reward f32[A] | child i32[A]      (24*A, padded to 64 B)
+// so one dependent step of a descent reads ONE contiguous record (A=9: two 128-B lines) and the lanes of a
+// group read each field coalesced.  Block e is the node expanded by simulation e-1 in every tree (lockstep),
+// block 0 is the root.  Only visit_count and prior are initialised at expansion; value_sum/reward/child of a
+// slot are written by the first backup through it (visited <=> expanded) and never read before.
+// Root priors are fp64 after the noise mix (agent.py:175) and live in root_prior[T][A] with the root's
+// action list root_action[T][A].
+//
+// Execution.  One group of G lanes per tree, G = the power of two >= A (2..64): 64/G trees per wavefront,
+// lanes stride over the children, (score, action) arg-max by __shfl_xor inside the group.  Every tree keeps
+// the same group -> workgroup -> XCD assignment in every launch, so its records stay in that XCD's L2.
+//
+// Numerics (SURVEY.md traps T1-T8): fp64 scores, fp32 priors/rewards widened, no FMA contraction
+// (compiled with -ffp-contract=off), 2*log(n+1) tabulated by the host libm, ties to the largest action,
+// all-NaN scores pick the first child, IEEE fp64 division.
+#include "mz_common.h"
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr int kBlockThreads = 256;
+constexpr int kPathShift = 12;                 // path entry = (block << 12) | child index
+constexpr int kMaxActions = 1 << kPathShift;   // 4096
+constexpr int kMaxSimulations = (1 << 19) - 2;
+
+struct PoolDev {
+    int T, A, N;
+    int has_bounds;
+    int RS;                    // record stride in bytes
+    size_t tree_stride;        // (N+1)*RS
+    char* blocks;
+    double* root_prior;        // [T][A]
+    int* root_action;          // [T][A]
+    int* n_root;               // [T]
+    int* root_count;           // [T]
+    double* root_vsum;         // [T]
+    double* mm_min;            // [T]
+    double* mm_max;            // [T]
+    int* path;                 // [T][N+1]
+    int* path_len;             // [T]
+    long long* sum_len;        // [T] cumulative sum of path lengths backed up (measurement)
+    long long* sims;           // [T] cumulative simulations backed up
+    int* err_flag;             // [1]
+    const double* log_table;   // [N+2]
+    const int* sum_leaf;       // NumPy pairwise-sum program for n = A: leaves (lo, n) ...
+    const int* sum_merge;      // ... and merges (dst, src)
+    int n_sum_leaf, n_sum_merge;
+    double discount, default_value, kmin, kmax;
+};
+
+__device__ __forceinline__ char* rec(const PoolDev& p, int tree, int e) {
+    return p.blocks + (size_t)tree * p.tree_stride + (size_t)e * (size_t)p.RS;
+}
+__device__ __forceinline__ double* f_vsum(const PoolDev& p, char* r) { return reinterpret_cast<double*>(r); }
+__device__ __forceinline__ int* f_count(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 8 * (size_t)p.A); }
+__device__ __forceinline__ float* f_prior(const PoolDev& p, char* r) { return reinterpret_cast<float*>(r + 12 * (size_t)p.A); }
+__device__ __forceinline__ float* f_reward(const PoolDev& p, char* r) { return reinterpret_cast<float*>(r + 16 * (size_t)p.A); }
+__device__ __forceinline__ int* f_child(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 20 * (size_t)p.A); }
+
+// ---------------------------------------------------------------------------------------------------
+// select_leaf (agent.py:177-190) for one tree by a group of G lanes.  Every lane of the wavefront calls
+// this (inactive lanes with active=false) because the reduction shuffles must be wave-uniform.
+// ---------------------------------------------------------------------------------------------------
+template <int G>
+__device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int* out_parent, int* out_action) {
+    int e = 0, np_ = 0, nchild = 0, depth = 0;
+    bool done = !active;
+    bool ident = false;            // MinMaxStats.normalize returns the value unchanged (utils.py:71-72)
+    double na = p.kmin, nd = p.kmax - p.kmin;
+    if (active) {
+        np_ = p.root_count[tree];
+        nchild = p.n_root[tree];
+        if (!p.has_bounds) {
+            const double mn = p.mm_min[tree], mx = p.mm_max[tree];
+            ident = (mx == mn);
+            na = mn;
+            nd = mx - mn;
+        }
+    }
+    for (int it = 0; it <= p.N; ++it) {          // a path holds at most N+1 nodes: every wave reaches the exit
+        if (!__any(!done)) break;
+        double bs = 0.0;
+        int bkey = -1;
+        int s0nan = 0;
+        char* r = nullptr;
+        if (!done) {
+            r = rec(p, tree, e);
+            const double* vs = f_vsum(p, r);
+            const int* cnt = f_count(p, r);
+            const float* pr = f_prior(p, r);
+            const float* rw = f_reward(p, r);
+            const double lt = p.log_table[np_];                       // 2*log(Np+1), config.py:159-160
+            const bool root = (e == 0);
+            for (int k = gl; k < nchild; k += G) {
+                const int c = cnt[k];
+                double exploit = p.default_value;                     // isnan(node.value), agent.py:188
+                if (c > 0) {
+                    const double val = vs[k] / (double)c;             // Node.value, agent.py:122
+                    if (val == val) exploit = (double)rw[k] + p.discount * val;
+                }
+                const double nrm = ident ? exploit : (exploit - na) / nd;          // utils.py:68-76
+                const double prior = root ? p.root_prior[(size_t)tree * p.A + k] : (double)pr[k];
+                const double sc = nrm + prior * (lt / (double)(c + 1));            // agent.py:189-190
+                const int act = root ? p.root_action[(size_t)tree * p.A + k] : k;
+                const int key = (act << 16) | k;
+                if (k == 0) s0nan = (sc != sc);
+                if (sc == sc && (bkey < 0 || sc > bs || (sc == bs && key > bkey))) {
+                    bs = sc;
+                    bkey = key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const double os = __shfl_xor(bs, off, G);
+            const int ok = __shfl_xor(bkey, off, G);
+            if (ok >= 0 && (bkey < 0 || os > bs || (os == bs && ok > bkey))) {
+                bs = os;
+                bkey = ok;
+            }
+        }
+        s0nan = __shfl(s0nan, 0, G);
+        if (!done) {
+            // Python's max() over (score, action, child) tuples never replaces a NaN-scored first element and
+            // never accepts a NaN-scored later one (agent.py:184): NaN first child wins, else the non-NaN arg-max.
+            const int k = (s0nan || bkey < 0) ? 0 : (bkey & 0xffff);
+            const int act = (e == 0) ? p.root_action[(size_t)tree * p.A + k] : k;
+            if (gl == 0) p.path[(size_t)tree * (p.N + 1) + depth] = (e << kPathShift) | k;
+            const int c = f_count(p, r)[k];
+            if (c > 0) {                     // visited <=> expanded: descend (agent.py:179-180)
+                np_ = c;
+                e = f_child(p, r)[k];
+                nchild = p.A;
+                ++depth;
+            } else {
+                done = true;
+                if (gl == 0) {
+                    out_parent[tree] = e;
+                    out_action[tree] = act;
+                    p.path_len[tree] = depth + 1;
+                }
+            }
+        }
+    }
+    if (active && !done && gl == 0) {        // unreachable for a consistent pool; never leave outputs unset
+        out_parent[tree] = -1;
+        out_action[tree] = -1;
+        p.path_len[tree] = 0;
+        atomicOr(p.err_flag, 1);
+    }
+    if (!active && gl == 0 && tree < p.T) {
+        out_parent[tree] = -1;
+        out_action[tree] = -1;
+    }
+}
+
+// NumPy float32 pairwise summation (trap T4) of a[0..A) by the lanes of one group.  The host compiled the
+// recursion for n = A into leaves (lo, n<=128) and merges (dst += src); lanes 0..7 are the eight strided
+// accumulators of a leaf.  `scratch` (>= n_sum_leaf floats) receives the leaf sums.  Returns the sum in
+// every lane.  Requires the group to have made a[] visible (workgroup fence + barrier by the caller).
+template <int G>
+__device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch, int gl) {
+    constexpr int W = G < 8 ? G : 8;
+    for (int s = 0; s < p.n_sum_leaf; ++s) {
+        const int lo = p.sum_leaf[2 * s], n = p.sum_leaf[2 * s + 1];
+        float res;
+        if (n < 8) {
+            res = 0.f;
+            if (gl == 0)
+                for (int i = 0; i < n; ++i) res += a[lo + i];
+        } else {
+            const int nfull = n - (n % 8);
+            float r = 0.f;
+            if (W == 8) {
+                if (gl < 8) {
+                    r = a[lo + gl];
+                    for (int i = 8; i < nfull; i += 8) r += a[lo + i + gl];
+                }
+                // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+                r += __shfl_xor(r, 1, W);
+                r += __shfl_xor(r, 2, W);
+                r += __shfl_xor(r, 4, W);
+                res = r;
+            } else {   // groups narrower than 8 lanes only exist for A <= 4 < 8: not reached
+                res = 0.f;
+            }
+            if (gl == 0)
+                for (int i = nfull; i < n; ++i) res += a[lo + i];
+        }
+        if (gl == 0) scratch[s] = res;
+    }
+    if (gl == 0) {
+        for (int m = 0; m < p.n_sum_merge; ++m) {
+            const int dst = p.sum_merge[2 * m], src = p.sum_merge[2 * m + 1];
+            scratch[dst] = scratch[dst] + scratch[src];
+        }
+    }
+    float total = (gl == 0) ? scratch[0] : 0.f;
+    return __shfl(total, 0, G);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// expand_node(leaf, all actions) + backpropagate(leaf, value)  (agent.py:208-211, 154-160, 192-196)
+// ---------------------------------------------------------------------------------------------------
+template <int G, bool LOGITS>
+__device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, int nb, const float* pol,
+                              const float* reward, const float* value) {
+    const int A = p.A;
+    int len = 0;
+    float rnew = 0.f;
+    double v = 0.0;
+    if (active) {
+        len = p.path_len[tree];
+        rnew = reward[tree];
+        v = (double)value[tree];
+        char* r = rec(p, tree, nb);
+        int* cnt = f_count(p, r);
+        float* pr = f_prior(p, r);
+        if (LOGITS) {
+            for (int k = gl; k < A; k += G) {
+                cnt[k] = 0;
+                pr[k] = expf(pol[(size_t)tree * A + k]);          // network.py:145, no max-subtraction
+            }
+        } else {
+            for (int k = gl; k < A; k += G) {
+                cnt[k] = 0;
+                pr[k] = pol[(size_t)tree * A + k];
+            }
+        }
+    }
+    if (LOGITS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        char* r = rec(p, active ? tree : 0, active ? nb : 0);
+        float total = numpy_sum_f32<G>(p, f_prior(p, r), f_reward(p, r), active ? gl : 1 << 30);
+        if (active) {
+            float* pr = f_prior(p, r);
+            for (int k = gl; k < A; k += G) pr[k] = pr[k] / total;   // network.py:146
+        }
+    }
+    // Backup chain leaf -> root.  Lane j of the group owns path position top-base-j, loads its slot, all lanes
+    // replay the fp64 recurrence value = reward + discount*value (agent.py:195) through shuffles.
+    const int top = len - 1;
+    double mn_l = std::numeric_limits<double>::infinity();
+    double mx_l = -std::numeric_limits<double>::infinity();
+    for (int base = 0;; base += G) {
+        const bool more = base < len;
+        if (!__any(more)) break;
+        const int pos = top - base - gl;
+        const bool has = more && pos >= 0;
+        int c = 0, k = 0;
+        double vs = 0.0;
+        float rw = 0.f;
+        char* r = nullptr;
+        if (has) {
+            const int slot = p.path[(size_t)tree * (p.N + 1) + pos];
+            k = slot & (kMaxActions - 1);
+            r = rec(p, tree, slot >> kPathShift);
+            c = f_count(p, r)[k];
+            if (c > 0) vs = f_vsum(p, r)[k];
+            rw = (pos == top) ? rnew : f_reward(p, r)[k];
+        }
+        const int n_here = more ? min(G, len - base) : 0;
+        double vin = v;
+        for (int j = 0; j < G; ++j) {
+            if (!__any(j < n_here)) break;
+            const float rj = __shfl(rw, j, G);
+            if (gl == j) vin = v;
+            if (j < n_here) v = (double)rj + p.discount * v;
+        }
+        if (has) {
+            c += 1;                                   // Node.update_value, agent.py:119-123
+            vs = vs + vin;
+            f_count(p, r)[k] = c;
+            f_vsum(p, r)[k] = vs;
+            const double mean = vs / (double)c;
+            if (mean > mx_l) mx_l = mean;             // MinMaxStats.update, utils.py:63-66
+            if (mean < mn_l) mn_l = mean;
+            if (pos == top) {                         // the leaf: now expanded (agent.py:156-157)
+                f_child(p, r)[k] = nb;
+                f_reward(p, r)[k] = rnew;
+            }
+        }
+    }
+    if (active && gl == 0) {                          // the root (reward None -> chain ends, agent.py:195)
+        const int rc = p.root_count[tree] + 1;
+        const double rvs = p.root_vsum[tree] + v;
+        p.root_count[tree] = rc;
+        p.root_vsum[tree] = rvs;
+        const double mean = rvs / (double)rc;
+        if (mean > mx_l) mx_l = mean;
+        if (mean < mn_l) mn_l = mean;
+        p.sum_len[tree] += len;
+        p.sims[tree] += 1;
+    }
+    if (!p.has_bounds) {
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const double omx = __shfl_xor(mx_l, off, G);
+            const double omn = __shfl_xor(mn_l, off, G);
+            if (omx > mx_l) mx_l = omx;
+            if (omn < mn_l) mn_l = omn;
+        }
+        if (active && gl == 0) {
+            if (mx_l > p.mm_max[tree]) p.mm_max[tree] = mx_l;
+            if (mn_l < p.mm_min[tree]) p.mm_min[tree] = mn_l;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void select_kernel(PoolDev p, int* out_parent, int* out_action) {
+    const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
+    const int tree = gid / G, gl = gid % G;
+    const bool active = tree < p.T && p.n_root[tree] > 0;
+    select_tree<G>(p, tree, active, gl, out_parent, out_action);
+}
+
+template <int G, bool LOGITS>
+__global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int nb, const float* pol,
+                                                                 const float* reward, const float* value) {
+    const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
+    const int tree = gid / G, gl = gid % G;
+    const bool active = tree < p.T && p.n_root[tree] > 0;
+    backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol, reward, value);
+}
+
+// expand+backprop of simulation s fused with select of simulation s+1: the group re-reads records it has
+// just written, so the writes are released/acquired at workgroup scope (same CU, same L1).
+template <int G, bool LOGITS>
+__global__ __launch_bounds__(kBlockThreads) void step_kernel(PoolDev p, int nb, const float* pol,
+                                                             const float* reward, const float* value,
+                                                             int* out_parent, int* out_action) {
+    const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
+    const int tree = gid / G, gl = gid % G;
+    const bool active = tree < p.T && p.n_root[tree] > 0;
+    backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol, reward, value);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    select_tree<G>(p, tree, active, gl, out_parent, out_action);
+}
+
+// Root expansion (agent.py:154-160 on the root; positional priors, trap T5).
+template <int G, bool LOGITS>
+__global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, const float* pol, const int* legal,
+                                                                     const int* n_legal) {
+    const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
+    const int tree = gid / G, gl = gid % G;
+    const int A = p.A;
+    const bool in = tree < p.T;
+    int n = 0;
+    if (in) {
+        n = n_legal ? n_legal[tree] : A;
+        if (n < 0 || n > A) {
+            n = 0;
+            if (gl == 0) atomicOr(p.err_flag, 2);
+        }
+    }
+    char* r = rec(p, in ? tree : 0, 0);
+    float total = 1.f;
+    if (LOGITS) {
+        // masked_policy over the FULL action axis (network.py:143-146): exp(logit) at legal actions, 0 elsewhere
+        if (in && n > 0) {
+            float* pr = f_prior(p, r);
+            for (int k = gl; k < A; k += G) pr[k] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (in && n > 0) {
+            float* pr = f_prior(p, r);
+            for (int k = gl; k < n; k += G) {
+                const int a = legal ? legal[(size_t)tree * A + k] : k;
+                if (a >= 0 && a < A) pr[a] = expf(pol[(size_t)tree * A + a]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        total = numpy_sum_f32<G>(p, f_prior(p, r), f_reward(p, r), (in && n > 0) ? gl : 1 << 30);
+    }
+    if (!in) return;
+    int* cnt = f_count(p, r);
+    for (int k = gl; k < n; k += G) {
+        int a = legal ? legal[(size_t)tree * A + k] : k;
+        if (a < 0 || a >= A) {
+            a = 0;
+            atomicOr(p.err_flag, 4);
+        }
+        cnt[k] = 0;
+        const float pk = LOGITS ? f_prior(p, r)[k] / total : pol[(size_t)tree * A + k];   // child k <- policy[k]
+        p.root_prior[(size_t)tree * A + k] = (double)pk;
+        p.root_action[(size_t)tree * A + k] = a;
+    }
+    if (gl == 0) {
+        p.n_root[tree] = n;
+        p.root_count[tree] = 0;
+        p.root_vsum[tree] = 0.0;
+        p.mm_min[tree] = std::numeric_limits<double>::infinity();    // utils.py:60-61
+        p.mm_max[tree] = -std::numeric_limits<double>::infinity();
+        p.path_len[tree] = 0;
+    }
+}
+
+__global__ void root_noise_kernel(PoolDev p, const double* noise, double frac) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)p.T * p.A) return;
+    const int tree = (int)(i / p.A), k = (int)(i % p.A);
+    if (k >= p.n_root[tree]) return;
+    p.root_prior[i] = p.root_prior[i] * (1 - frac) + noise[i] * frac;     // agent.py:175 (fp64, uncontracted)
+}
+
+__global__ void root_stats_kernel(PoolDev p, int* visits, double* root_value, double* minmax, float* policy) {
+    const int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= p.T) return;
+    const int A = p.A, n = p.n_root[tree];
+    const int rc = p.root_count[tree];
+    if (visits)
+        for (int a = 0; a < A; ++a) visits[(size_t)tree * A + a] = 0;
+    if (policy)
+        for (int a = 0; a < A; ++a) policy[(size_t)tree * A + a] = 0.f;
+    const int* cnt = f_count(p, rec(p, tree, 0));
+    for (int k = 0; k < n; ++k) {
+        const int a = p.root_action[(size_t)tree * A + k];
+        const int c = cnt[k];
+        if (visits) visits[(size_t)tree * A + a] = c;
+        if (policy) policy[(size_t)tree * A + a] = (float)((double)c / (double)rc);    // agent.py:230
+    }
+    if (root_value)
+        root_value[tree] = rc > 0 ? p.root_vsum[tree] / (double)rc : std::numeric_limits<double>::quiet_NaN();
+    if (minmax) {
+        minmax[2 * tree] = p.mm_min[tree];
+        minmax[2 * tree + 1] = p.mm_max[tree];
+    }
+}
+
+// softmax_sample (agent.py:162-168) with CPython's random.choices arithmetic; one lane per tree.
+__global__ void select_action_kernel(PoolDev p, const double* u, const double* temperature, int* out_action) {
+    const int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= p.T) return;
+    const int A = p.A, n = p.n_root[tree];
+    if (n <= 0) {
+        out_action[tree] = -1;
+        return;
+    }
+    const int* cnt = f_count(p, rec(p, tree, 0));
+    const int* act = p.root_action + (size_t)tree * A;
+    const double t = temperature[tree];
+    if (t == 0.0) {                               // max((count, action)): ties to the largest action
+        int bc = cnt[0], ba = act[0];
+        for (int k = 1; k < n; ++k) {
+            const int c = cnt[k], a = act[k];
+            if (c > bc || (c == bc && a > ba)) {
+                bc = c;
+                ba = a;
+            }
+        }
+        out_action[tree] = ba;
+        return;
+    }
+    const double inv_t = 1 / t;
+    auto weight = [&](int c) -> double {
+        if (inv_t == 1.0) return (double)c;       // pow(c, 1.0) == c exactly
+        if (inv_t == 2.0) return (double)c * (double)c;
+        if (inv_t == 4.0) {
+            const double c2 = (double)c * (double)c;
+            return c2 * c2;
+        }
+        return pow((double)c, inv_t);
+    };
+    double total = 0.0;                           // itertools.accumulate: sequential fp64 sums
+    for (int k = 0; k < n; ++k) total = (k == 0) ? weight(cnt[0]) : total + weight(cnt[k]);
+    const double x = u[tree] * (total + 0.0);
+    // bisect_right(cum, x, 0, n-1) == number of cum[i] <= x for i < n-1 (cum is non-decreasing)
+    double cum = 0.0;
+    int idx = 0;
+    for (int k = 0; k < n - 1; ++k) {
+        cum = (k == 0) ? weight(cnt[0]) : cum + weight(cnt[k]);
+        if (!(x < cum)) idx = k + 1;
+        else break;
+    }
+    out_action[tree] = act[idx];
+}
+
+__global__ void sum_counters_kernel(PoolDev p, long long* out2) {
+    __shared__ long long s_len[kBlockThreads], s_sims[kBlockThreads];
+    long long a = 0, b = 0;
+    for (int t = threadIdx.x; t < p.T; t += kBlockThreads) {
+        a += p.sims[t];
+        b += p.sum_len[t];
+    }
+    s_sims[threadIdx.x] = a;
+    s_len[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = kBlockThreads / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            s_sims[threadIdx.x] += s_sims[threadIdx.x + off];
+            s_len[threadIdx.x] += s_len[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = s_sims[0];
+        out2[1] = s_len[0];
+    }
+}
+
+int group_width(int A) {
+    int g = 2;
+    while (g < A && g < 64) g <<= 1;
+    return g;
+}
+
+// NumPy pairwise_sum recursion for n elements -> leaves (lo,n) in order + merges (dst,src) in evaluation order.
+int build_sum_program(int lo, int n, std::vector<int>& leaves, std::vector<int>& merges) {
+    if (n <= 128) {
+        leaves.push_back(lo);
+        leaves.push_back(n);
+        return (int)leaves.size() / 2 - 1;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const int left = build_sum_program(lo, n2, leaves, merges);
+    const int right = build_sum_program(lo + n2, n - n2, leaves, merges);
+    merges.push_back(left);
+    merges.push_back(right);
+    return left;
+}
+
+}  // namespace
+
+struct mz_pool {
+    PoolDev dev{};
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int G = 2;
+    int blocks_in_use = 0;     // 0 = roots not expanded; else simulations done + 1
+    bool pending = false;      // a select is waiting for its expand_backprop
+    long long select_launches = 0, backprop_launches = 0;
+    size_t bytes = 0;
+    std::vector<void*> allocations;
+    long long* counter_scratch = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mz_pool* pool, T** out, size_t count) {
+    void* ptr = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&ptr, bytes ? bytes : 16);
+    if (e != hipSuccess)
+        return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes,
+                        hipGetErrorString(e));
+    pool->allocations.push_back(ptr);
+    pool->bytes += bytes;
+    *out = static_cast<T*>(ptr);
+    return MZ_OK;
+}
+
+#define MZ_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != MZ_OK) return _s; \
+    } while (0)
+
+int grid_for(const mz_pool* pool) {
+    const int trees_per_block = kBlockThreads / pool->G;
+    return (pool->dev.T + trees_per_block - 1) / trees_per_block;
+}
+
+template <typename F>
+void dispatch_group(int G, F&& f) {
+    switch (G) {
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        case 8: f(std::integral_constant<int, 8>{}); break;
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 32: f(std::integral_constant<int, 32>{}); break;
+        default: f(std::integral_constant<int, 64>{}); break;
+    }
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return MZ_OK;
+}
+
+int expand_roots_impl(mz_pool* pool, const float* pol, const int32_t* legal, const int32_t* n_legal, bool logits) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    MZ_REQUIRE(pol != nullptr, "priors/logits is NULL");
+    MZ_HIP(hipSetDevice(pool->device));
+    const int grid = grid_for(pool);
+    dispatch_group(pool->G, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        if (logits)
+            expand_roots_kernel<G, true><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal);
+        else
+            expand_roots_kernel<G, false><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal);
+    });
+    MZ_TRY(check_launch("expand_roots_kernel"));
+    pool->blocks_in_use = 1;
+    pool->pending = false;
+    return MZ_OK;
+}
+
+int backprop_impl(mz_pool* pool, const float* pol, const float* reward, const float* value, bool logits,
+                  int32_t* out_parent, int32_t* out_action, bool fused) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    MZ_REQUIRE(pol && reward && value, "priors/logits, reward and value must be non-NULL");
+    if (fused) MZ_REQUIRE(out_parent && out_action, "out_parent_block and out_action must be non-NULL");
+    if (!pool->pending) return mz::fail(MZ_ERR_STATE, "expand_backprop without a preceding select");
+    const int nb = pool->blocks_in_use;
+    if (nb > pool->dev.N) return mz::fail(MZ_ERR_STATE, "pool is full: %d simulations done", nb - 1);
+    if (fused && nb + 1 > pool->dev.N)
+        return mz::fail(MZ_ERR_STATE, "mz_step on the last simulation (%d of %d): use mz_expand_backprop", nb,
+                        pool->dev.N);
+    MZ_HIP(hipSetDevice(pool->device));
+    const int grid = grid_for(pool);
+    dispatch_group(pool->G, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        hipStream_t st = pool->stream;
+        if (fused && logits)
+            step_kernel<G, true><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
+        else if (fused)
+            step_kernel<G, false><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
+        else if (logits)
+            backprop_kernel<G, true><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value);
+        else
+            backprop_kernel<G, false><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value);
+    });
+    MZ_TRY(check_launch(fused ? "step_kernel" : "backprop_kernel"));
+    if (fused) pool->select_launches++;
+    pool->backprop_launches++;
+    pool->blocks_in_use = nb + 1;
+    pool->pending = fused;
+    return MZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_pool) {
+    MZ_REQUIRE(cfg != nullptr && out_pool != nullptr, "config/out_pool is NULL");
+    *out_pool = nullptr;
+    MZ_REQUIRE(cfg->num_trees >= 1, "num_trees must be >= 1 (got %d)", cfg->num_trees);
+    MZ_REQUIRE(cfg->num_actions >= 1 && cfg->num_actions <= kMaxActions, "num_actions must be in [1, %d] (got %d)",
+               kMaxActions, cfg->num_actions);
+    MZ_REQUIRE(cfg->max_simulations >= 1 && cfg->max_simulations <= kMaxSimulations,
+               "max_simulations must be in [1, %d] (got %d)", kMaxSimulations, cfg->max_simulations);
+    MZ_REQUIRE(cfg->num_players == 1 || cfg->num_players == 2, "num_players must be 1 or 2 (got %d)",
+               cfg->num_players);
+    if (cfg->has_known_bounds)
+        MZ_REQUIRE(cfg->known_max == cfg->known_max && cfg->known_min == cfg->known_min, "known bounds are NaN");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mz::fail(MZ_ERR_NO_DEVICE, "no HIP device visible: libmzhip has no CPU fallback");
+    }
+    mz_pool* pool = new (std::nothrow) mz_pool();
+    if (!pool) return mz::fail(MZ_ERR_OOM, "host allocation failed");
+    int status = MZ_OK;
+    do {
+        hipError_t e = hipGetDevice(&pool->device);
+        if (e != hipSuccess) {
+            status = mz::fail(MZ_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+            break;
+        }
+        pool->stream = static_cast<hipStream_t>(stream);
+        PoolDev& d = pool->dev;
+        d.T = cfg->num_trees;
+        d.A = cfg->num_actions;
+        d.N = cfg->max_simulations;
+        d.has_bounds = cfg->has_known_bounds ? 1 : 0;
+        d.RS = (24 * d.A + 63) / 64 * 64;
+        d.tree_stride = (size_t)(d.N + 1) * (size_t)d.RS;
+        d.discount = cfg->num_players == 2 ? -cfg->discount : cfg->discount;      // agent.py:150-152
+        d.default_value = cfg->default_value;
+        d.kmin = cfg->known_min;
+        d.kmax = cfg->known_max;
+        pool->G = group_width(d.A);
+        const size_t TA = (size_t)d.T * d.A;
+        double* log_dev = nullptr;
+        int* leaf_dev = nullptr;
+        int* merge_dev = nullptr;
+        if ((status = dev_alloc(pool, &d.blocks, (size_t)d.T * d.tree_stride)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.root_prior, TA)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.root_action, TA)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.n_root, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.root_count, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.root_vsum, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.mm_min, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.mm_max, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.path, (size_t)d.T * (d.N + 1))) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.path_len, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.sum_len, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.sims, (size_t)d.T)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &d.err_flag, (size_t)1)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &log_dev, (size_t)d.N + 2)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &pool->counter_scratch, (size_t)2)) != MZ_OK) break;
+        std::vector<double> table(d.N + 2);
+        for (int n = 0; n < d.N + 2; ++n)
+            table[n] = cfg->log_table ? cfg->log_table[n] : 2 * std::log((double)(n + 1));   // config.py:160
+        std::vector<int> leaves, merges;
+        build_sum_program(0, d.A, leaves, merges);
+        d.n_sum_leaf = (int)leaves.size() / 2;
+        d.n_sum_merge = (int)merges.size() / 2;
+        if ((status = dev_alloc(pool, &leaf_dev, leaves.size())) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &merge_dev, merges.size() + 2)) != MZ_OK) break;
+        hipError_t err = hipSuccess;
+#define MZ_CREATE_HIP(expr)                                                                      \
+    if ((err = (expr)) != hipSuccess) {                                                          \
+        status = mz::fail(MZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(err));           \
+        break;                                                                                   \
+    }
+        MZ_CREATE_HIP(hipMemcpy(log_dev, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
+        MZ_CREATE_HIP(hipMemcpy(leaf_dev, leaves.data(), leaves.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!merges.empty())
+            MZ_CREATE_HIP(hipMemcpy(merge_dev, merges.data(), merges.size() * sizeof(int), hipMemcpyHostToDevice));
+        MZ_CREATE_HIP(hipMemset(d.n_root, 0, (size_t)d.T * sizeof(int)));
+        MZ_CREATE_HIP(hipMemset(d.sum_len, 0, (size_t)d.T * sizeof(long long)));
+        MZ_CREATE_HIP(hipMemset(d.sims, 0, (size_t)d.T * sizeof(long long)));
+        MZ_CREATE_HIP(hipMemset(d.err_flag, 0, sizeof(int)));
+        MZ_CREATE_HIP(hipMemset(d.path_len, 0, (size_t)d.T * sizeof(int)));
+#undef MZ_CREATE_HIP
+        d.log_table = log_dev;
+        d.sum_leaf = leaf_dev;
+        d.sum_merge = merge_dev;
+    } while (0);
+    if (status != MZ_OK) {
+        for (void* ptr : pool->allocations) (void)hipFree(ptr);
+        delete pool;
+        return status;
+    }
+    *out_pool = pool;
+    return MZ_OK;
+}
+
+int mz_pool_destroy(mz_pool_t* pool) {
+    if (!pool) return MZ_OK;
+    (void)hipSetDevice(pool->device);
+    (void)hipStreamSynchronize(pool->stream);
+    for (void* ptr : pool->allocations) (void)hipFree(ptr);
+    delete pool;
+    return MZ_OK;
+}
+
+int mz_pool_set_stream(mz_pool_t* pool, void* stream) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    pool->stream = static_cast<hipStream_t>(stream);
+    return MZ_OK;
+}
+
+int mz_pool_reset(mz_pool_t* pool) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    pool->blocks_in_use = 0;     // per-tree state is re-initialised by the next mz_expand_roots
+    pool->pending = false;
+    return MZ_OK;
+}
+
+int mz_expand_roots(mz_pool_t* pool, const float* priors, const int32_t* legal, const int32_t* n_legal) {
+    return expand_roots_impl(pool, priors, legal, n_legal, false);
+}
+
+int mz_expand_roots_logits(mz_pool_t* pool, const float* logits, const int32_t* legal, const int32_t* n_legal) {
+    return expand_roots_impl(pool, logits, legal, n_legal, true);
+}
+
+int mz_add_root_noise(mz_pool_t* pool, const double* noise, double frac) {
+    MZ_REQUIRE(pool != nullptr && noise != nullptr, "pool/noise is NULL");
+    if (pool->blocks_in_use != 1) return mz::fail(MZ_ERR_STATE, "add_root_noise must directly follow expand_roots");
+    MZ_HIP(hipSetDevice(pool->device));
+    const size_t n = (size_t)pool->dev.T * pool->dev.A;
+    hipLaunchKernelGGL(root_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pool->stream, pool->dev,
+                       noise, frac);
+    return check_launch("root_noise_kernel");
+}
+
+int mz_select(mz_pool_t* pool, int32_t* out_parent_block, int32_t* out_action) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    MZ_REQUIRE(out_parent_block && out_action, "out_parent_block and out_action must be non-NULL");
+    if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "select before expand_roots");
+    if (pool->pending) return mz::fail(MZ_ERR_STATE, "select while a previous select awaits expand_backprop");
+    if (pool->blocks_in_use > pool->dev.N)
+        return mz::fail(MZ_ERR_STATE, "pool is full: %d simulations done", pool->blocks_in_use - 1);
+    MZ_HIP(hipSetDevice(pool->device));
+    const int grid = grid_for(pool);
+    dispatch_group(pool->G, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        select_kernel<G><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, out_parent_block, out_action);
+    });
+    MZ_TRY(check_launch("select_kernel"));
+    pool->select_launches++;
+    pool->pending = true;
+    return MZ_OK;
+}
+
+int mz_expand_backprop(mz_pool_t* pool, const float* priors, const float* reward, const float* value) {
+    return backprop_impl(pool, priors, reward, value, false, nullptr, nullptr, false);
+}
+
+int mz_expand_backprop_logits(mz_pool_t* pool, const float* logits, const float* reward, const float* value) {
+    return backprop_impl(pool, logits, reward, value, true, nullptr, nullptr, false);
+}
+
+int mz_step(mz_pool_t* pool, const float* priors, const float* reward, const float* value, int32_t* out_parent_block,
+            int32_t* out_action) {
+    return backprop_impl(pool, priors, reward, value, false, out_parent_block, out_action, true);
+}
+
+int mz_step_logits(mz_pool_t* pool, const float* logits, const float* reward, const float* value,
+                   int32_t* out_parent_block, int32_t* out_action) {
+    return backprop_impl(pool, logits, reward, value, true, out_parent_block, out_action, true);
+}
+
+int mz_root_stats(mz_pool_t* pool, int32_t* visits, double* root_value, double* minmax, float* policy) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "root_stats before expand_roots");
+    MZ_HIP(hipSetDevice(pool->device));
+    hipLaunchKernelGGL(root_stats_kernel, dim3((pool->dev.T + 63) / 64), dim3(64), 0, pool->stream, pool->dev, visits,
+                       root_value, minmax, policy);
+    return check_launch("root_stats_kernel");
+}
+
+int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature, int32_t* out_action) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    MZ_REQUIRE(u && temperature && out_action, "u, temperature and out_action must be non-NULL");
+    if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "select_action before expand_roots");
+    MZ_HIP(hipSetDevice(pool->device));
+    hipLaunchKernelGGL(select_action_kernel, dim3((pool->dev.T + 63) / 64), dim3(64), 0, pool->stream, pool->dev, u,
+                       temperature, out_action);
+    return check_launch("select_action_kernel");
+}
+
+int mz_pool_counters(mz_pool_t* pool, int64_t* out4_host) {
+    MZ_REQUIRE(pool != nullptr && out4_host != nullptr, "pool/out is NULL");
+    MZ_HIP(hipSetDevice(pool->device));
+    hipLaunchKernelGGL(sum_counters_kernel, dim3(1), dim3(kBlockThreads), 0, pool->stream, pool->dev,
+                       pool->counter_scratch);
+    MZ_TRY(check_launch("sum_counters_kernel"));
+    long long host[2] = {0, 0};
+    MZ_HIP(hipMemcpyAsync(host, pool->counter_scratch, sizeof(host), hipMemcpyDeviceToHost, pool->stream));
+    int err = 0;
+    MZ_HIP(hipMemcpyAsync(&err, pool->dev.err_flag, sizeof(int), hipMemcpyDeviceToHost, pool->stream));
+    MZ_HIP(hipStreamSynchronize(pool->stream));
+    if (err != 0) return mz::fail(MZ_ERR_INVALID_ARG, "device-side validation failed (flags 0x%x): bad legal/n_legal", err);
+    out4_host[0] = host[0];
+    out4_host[1] = host[1];
+    out4_host[2] = pool->select_launches;
+    out4_host[3] = pool->backprop_launches;
+    return MZ_OK;
+}
+
+int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* out_num_children, int32_t* actions,
+                       int32_t* count, double* value_sum, double* prior, float* reward, int32_t* child) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    const PoolDev& d = pool->dev;
+    MZ_REQUIRE(tree >= 0 && tree < d.T, "tree %d out of range [0,%d)", tree, d.T);
+    MZ_REQUIRE(block >= 0 && block < pool->blocks_in_use, "block %d out of range [0,%d)", block, pool->blocks_in_use);
+    MZ_HIP(hipSetDevice(pool->device));
+    MZ_HIP(hipStreamSynchronize(pool->stream));
+    const int A = d.A;
+    int n = A;
+    if (block == 0) MZ_HIP(hipMemcpy(&n, d.n_root + tree, sizeof(int), hipMemcpyDeviceToHost));
+    if (out_num_children) *out_num_children = n;
+    std::vector<char> recbuf(d.RS);
+    MZ_HIP(hipMemcpy(recbuf.data(), d.blocks + (size_t)tree * d.tree_stride + (size_t)block * d.RS, d.RS,
+                     hipMemcpyDeviceToHost));
+    const double* vs = reinterpret_cast<const double*>(recbuf.data());
+    const int* cnt = reinterpret_cast<const int*>(recbuf.data() + 8 * (size_t)A);
+    const float* pr = reinterpret_cast<const float*>(recbuf.data() + 12 * (size_t)A);
+    const float* rw = reinterpret_cast<const float*>(recbuf.data() + 16 * (size_t)A);
+    const int* ch = reinterpret_cast<const int*>(recbuf.data() + 20 * (size_t)A);
+    std::vector<double> rprior(A);
+    std::vector<int> ract(A);
+    if (block == 0) {
+        MZ_HIP(hipMemcpy(rprior.data(), d.root_prior + (size_t)tree * A, A * sizeof(double), hipMemcpyDeviceToHost));
+        MZ_HIP(hipMemcpy(ract.data(), d.root_action + (size_t)tree * A, A * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < n; ++k) {
+        const bool visited = cnt[k] > 0;
+        if (actions) actions[k] = block == 0 ? ract[k] : k;
+        if (count) count[k] = cnt[k];
+        if (value_sum) value_sum[k] = visited ? vs[k] : 0.0;
+        if (prior) prior[k] = block == 0 ? rprior[k] : (double)pr[k];
+        if (reward) reward[k] = visited ? rw[k] : std::numeric_limits<float>::quiet_NaN();
+        if (child) child[k] = visited ? ch[k] : -1;
+    }
+    return MZ_OK;
+}
+
+int mz_pool_num_blocks(mz_pool_t* pool) { return pool ? pool->blocks_in_use : 0; }
+
+int64_t mz_pool_bytes(mz_pool_t* pool) { return pool ? (int64_t)pool->bytes : 0; }
+
+}  // extern "C"

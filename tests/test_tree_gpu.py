@@ -1,0 +1,162 @@
+"""HIP tree pool (through the C ABI) against the reference fixtures and the plain-C oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import TREE_FIXTURES, load_golden
+from helpers import (NumpyAdapter, TorchAdapter, assert_blocks_match_fixture, assert_matches_fixture,
+                     assert_same_search, fixture_kwargs, run_fixture_on_pool, run_synthetic_on_pool,
+                     synthetic_inputs)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ad():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return TorchAdapter('cuda')
+
+
+def hip_pool(**kw):
+    from muzero_amd.tree_pool import TreePool
+    return TreePool(**kw)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('name', TREE_FIXTURES)
+def test_hip_pool_matches_reference_fixture(name, fused, ad):
+    fx = load_golden(name)
+    pool = hip_pool(**fixture_kwargs(fx, num_trees=5))
+    res = run_fixture_on_pool(pool, fx, ad, fused=fused)
+    assert_matches_fixture(res, fx)
+    assert_blocks_match_fixture(pool, fx, tree=4)
+    pool.close()
+
+
+CASES = [
+    # T, A, N, players, discount, default, bounds, reward_mode, legal_mode      (BASELINE.json configs, reduced T)
+    dict(T=64, A=2, N=50, players=1, discount=0.99, default=50.0, bounds=(0.0, 100.0), reward='uniform', legal='all'),
+    dict(T=200, A=9, N=25, players=2, discount=1.0, default=0.0, bounds=(-1.0, 1.0), reward='tanh', legal='ragged'),
+    dict(T=300, A=18, N=50, players=1, discount=0.997, default=0.0, bounds=None, reward='uniform', legal='all'),
+    dict(T=33, A=18, N=50, players=1, discount=0.997, default=0.0, bounds=None, reward='uniform', legal='ragged'),
+    dict(T=24, A=362, N=120, players=2, discount=1.0, default=0.0, bounds=(-1.0, 1.0), reward='zero', legal='all'),
+    dict(T=7, A=362, N=60, players=2, discount=1.0, default=0.0, bounds=None, reward='tanh', legal='ragged'),
+    dict(T=5, A=1, N=10, players=1, discount=0.9, default=0.0, bounds=None, reward='uniform', legal='all'),
+    dict(T=9, A=65, N=40, players=1, discount=0.9, default=0.3, bounds=(-2.0, 3.0), reward='tanh', legal='ragged'),
+    dict(T=3, A=700, N=20, players=1, discount=0.9, default=0.0, bounds=None, reward='uniform', legal='ragged'),
+]
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('case', CASES, ids=lambda c: f"T{c['T']}_A{c['A']}_N{c['N']}_{c['legal']}")
+def test_hip_pool_matches_c_oracle(case, fused, ad):
+    from oracle import c_oracle
+    inp = synthetic_inputs(case['T'], case['A'], case['N'], seed=1234 + case['A'], reward_mode=case['reward'],
+                           legal_mode=case['legal'], value_scale=100.0 if case['default'] == 50.0 else 1.0)
+    kw = dict(num_trees=case['T'], num_actions=case['A'], max_simulations=case['N'], num_players=case['players'],
+              discount=case['discount'], default_value=case['default'], known_bounds=case['bounds'])
+    want = run_synthetic_on_pool(c_oracle.OraclePool(**kw), inp, NumpyAdapter, temperature=1.0)
+    pool = hip_pool(**kw)
+    got = run_synthetic_on_pool(pool, inp, ad, fused=fused, temperature=1.0)
+    assert_same_search(got, want)
+    # temperature 0 (arg-max with ties to the largest action) on the same finished trees
+    opool = c_oracle.OraclePool(**kw)
+    run_synthetic_on_pool(opool, inp, NumpyAdapter)
+    np.testing.assert_array_equal(ad.get(pool.select_action(ad.put(inp['u']), 0.0)),
+                                  opool.select_action(inp['u'], 0.0))
+    # a few whole trees, block by block
+    for t in range(0, case['T'], max(1, case['T'] // 3)):
+        if inp['n_legal'][t] == 0:
+            continue
+        for e in range(0, case['N'] + 1, 7):
+            a, b = pool.read_block(t, e), opool.read_block(t, e)
+            for key in ('actions', 'count', 'value_sum', 'prior', 'child'):
+                np.testing.assert_array_equal(a[key], b[key], err_msg=f'tree {t} block {e} {key}')
+            vis = a['count'] > 0
+            np.testing.assert_array_equal(a['reward'][vis], b['reward'][vis])
+    pool.close()
+
+
+def test_pool_is_reusable_across_moves(ad):
+    """reset() + expand_roots() starts a fresh search in the same memory (agent.py:220-221: no tree reuse)."""
+    from oracle import c_oracle
+    kw = dict(num_trees=40, num_actions=9, max_simulations=25, num_players=2, discount=1.0, default_value=0.0,
+              known_bounds=None)
+    pool = hip_pool(**kw)
+    for move in range(3):
+        inp = synthetic_inputs(40, 9, 25, seed=50 + move, reward_mode='tanh', legal_mode='ragged')
+        pool.reset()
+        got = run_synthetic_on_pool(pool, inp, ad, fused=bool(move % 2))
+        want = run_synthetic_on_pool(c_oracle.OraclePool(**kw), inp, NumpyAdapter)
+        got['counters'][:2] -= move * 0       # counters are cumulative on the HIP pool
+        for key in ('trace_parent', 'trace_action', 'visits', 'policy', 'action', 'root_value', 'minmax'):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f'move {move} {key}')
+    pool.close()
+
+
+def test_logits_entry_points_within_exp_tolerance(ad):
+    """mz_*_logits computes masked_policy on the device; expf vs NumPy's SIMD exp differ by <=2 ulp (trap T4),
+    so priors are compared to 4 ulp (stated tolerance: rtol 5e-7) instead of bit for bit."""
+    T, A, N = 50, 18, 3
+    inp = synthetic_inputs(T, A, N, seed=77, legal_mode='ragged')
+    pool = hip_pool(num_trees=T, num_actions=A, max_simulations=N, known_bounds=None)
+    pool.expand_roots(ad.put(inp['logits'][0]), ad.put(inp['legal']), ad.put(inp['n_legal']), logits=True)
+    for t in range(T):
+        nl = int(inp['n_legal'][t])
+        if nl == 0:
+            continue
+        b = pool.read_block(t, 0)
+        np.testing.assert_allclose(b['prior'], inp['priors'][0, t, :nl].astype(np.float64), rtol=5e-7, atol=0)
+    pool.select()
+    pool.expand_backprop(ad.put(inp['logits'][1]), ad.put(inp['rewards'][1]), ad.put(inp['values'][1]), logits=True)
+    for t in range(T):
+        if inp['n_legal'][t] == 0:
+            continue
+        b = pool.read_block(t, 1)
+        np.testing.assert_allclose(b['prior'], inp['priors'][1, t].astype(np.float64), rtol=5e-7, atol=0)
+    pool.close()
+
+
+def test_logits_wide_action_space(ad):
+    T, A = 4, 362
+    inp = synthetic_inputs(T, A, 2, seed=78)
+    pool = hip_pool(num_trees=T, num_actions=A, max_simulations=2, known_bounds=(-1.0, 1.0), num_players=2)
+    pool.expand_roots(ad.put(inp['logits'][0]), logits=True)
+    for t in range(T):
+        np.testing.assert_allclose(pool.read_block(t, 0)['prior'], inp['priors'][0, t].astype(np.float64), rtol=5e-7)
+    pool.select()
+    pool.expand_backprop(ad.put(inp['logits'][1]), ad.put(inp['rewards'][1]), ad.put(inp['values'][1]), logits=True)
+    for t in range(T):
+        np.testing.assert_allclose(pool.read_block(t, 1)['prior'], inp['priors'][1, t].astype(np.float64), rtol=5e-7)
+    pool.close()
+
+
+def test_call_sequence_errors(ad):
+    import torch
+    from muzero_amd.exceptions import MuZeroError, MuZeroHipError
+    pool = hip_pool(num_trees=4, num_actions=3, max_simulations=2)
+    z = lambda *s: torch.zeros(*s, device='cuda')
+    with pytest.raises(MuZeroHipError):
+        pool.select()                                    # before expand_roots
+    pool.expand_roots(torch.full((4, 3), 1 / 3, device='cuda'))
+    with pytest.raises(MuZeroHipError):
+        pool.expand_backprop(z(4, 3), z(4), z(4))        # no select pending
+    pool.select()
+    with pytest.raises(MuZeroHipError):
+        pool.select()                                    # select twice
+    with pytest.raises(MuZeroError):
+        pool.expand_backprop(z(4, 2), z(4), z(4))        # wrong shape is rejected on the host
+    with pytest.raises(MuZeroError):
+        pool.expand_backprop(z(4, 3).double(), z(4), z(4))
+    pool.step(torch.full((4, 3), 1 / 3, device='cuda'), z(4), z(4))
+    with pytest.raises(MuZeroHipError):
+        pool.step(z(4, 3), z(4), z(4))                   # step on the last simulation
+    pool.expand_backprop(torch.full((4, 3), 1 / 3, device='cuda'), z(4), z(4))
+    with pytest.raises(MuZeroHipError):
+        pool.select()                                    # pool full (N = 2)
+    assert int(pool.root_stats()[0].sum()) == 8
+    with pytest.raises(MuZeroHipError):
+        hip_pool(num_trees=0, num_actions=3, max_simulations=2)
+    with pytest.raises(MuZeroHipError):
+        hip_pool(num_trees=1, num_actions=5000, max_simulations=2)
+    pool.close()
