@@ -1,13 +1,881 @@
-// placeholder until the fused inference kernels land (same session)
+// Fused inference kernels for the two reference networks (gfx950, fp32-input MFMA).
+//
+// Replaces, in the reference (file:line relative to /root/reference):
+//   Network.initial_inference / recurrent_inference     network.py:209-254
+//   one_hot_tensor_encoder / binary_plane_encoder        network.py:14-40, 88-104
+//   scalar_to_support_model (CartPole preprocessing)     network.py:107-116, utils.py:138-143
+//   split_batch + ScalarConfig.to_scalar                 network.py:165-174, config.py:25-40, utils.py:146-148
+//   TicTacToeNetwork layer stacks                        games/tictactoe.py:179-213
+//   CartPoleNetwork layer stacks                         games/cartpole.py:92-132
+//   the leaf.parent.hidden_state gather of run_mcts      agent.py:204
+//
+// Building block: gemm64<K>() -- a 256-thread workgroup multiplies a 64-row activation tile held in LDS
+// (row stride K+4 floats: ds_read_b128 conflict-free) by a [K][128] weight matrix streamed from L2 in a
+// fragment-ordered packing ([K/8][128][8], one coalesced 1-KiB load per wave per 8 k's), with
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain: results stay within 1e-5 of the fp64 oracle).  Each wave owns
+// 32 output columns x 64 rows (two 32x32 accumulators), so a weight fragment feeds two MFMAs.
+//
+// TicTacToe (hidden = 3x3x128):
+//   kernel A (per 64 games x 1 board cell): 3x3 `same` conv as up to 9 chained gemm64 over the neighbour cells'
+//     hidden rows, gathered straight from the [N+1][T][H] hidden tensor by parent block (no gather copy); the
+//     one-hot action planes collapse into a per-(action, cell) bias table; Dense 128->128; writes hidden',
+//     the reward-head partial dot and the prediction conv's per-cell partial product.
+//   kernel B (per 64 games): sums the nine partials, Dense 128->128, value/policy/reward heads.
+// CartPole (hidden = 128): one kernel per call, a chain of gemm64 (binary action plane -> bias vector),
+//   softmax over the 101-bin value support and support_to_scalar fused in the epilogue.
 #include "mz_common.h"
-struct mz_net { int kind; };
-extern "C" {
-int64_t mz_net_num_weights(int32_t) { return 0; }
-int32_t mz_net_hidden_size(int32_t) { return 0; }
-int mz_net_create(int32_t, const float*, int64_t, int64_t, void*, mz_net_t**) { return mz::fail(MZ_ERR_STATE, "networks not built yet"); }
-int mz_net_destroy(mz_net_t*) { return MZ_OK; }
-int mz_net_set_stream(mz_net_t*, void*) { return MZ_OK; }
-int64_t mz_net_training_steps(mz_net_t*) { return 0; }
-int mz_infer_initial(mz_net_t*, int32_t, const float*, float*, float*, float*, float*) { return mz::fail(MZ_ERR_STATE, "networks not built yet"); }
-int mz_infer_recurrent(mz_net_t*, int32_t, const float*, const int32_t*, int64_t, const int32_t*, float*, float*, float*, float*, float*) { return mz::fail(MZ_ERR_STATE, "networks not built yet"); }
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;
+constexpr int kRows = 64;          // games per workgroup tile
+constexpr int kLd = 132;           // LDS row stride in floats for K = 128 (33 16-B slots: odd -> conflict-free)
+
+// C/D element (m-tile m, register r) of a 32x32x2 accumulator held by lane `lane`: row within the 64-row tile
+__device__ __forceinline__ int acc_row(int m, int r, int lane) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// acc[2] += sA[64][K] (LDS, stride lda) * W[K][128], W packed as Wp[K/8][128][8]; this wave: columns 32*wave..+31.
+template <int K>
+__device__ __forceinline__ void gemm64(const float* sA, int lda, const float* __restrict__ Wp, f32x16 (&acc)[2],
+                                       int lane, int wave) {
+    constexpr int KB = K / 8;
+    const int n = wave * 32 + (lane & 31), kh = lane >> 5;
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + n * 2 + kh;      // + kb * 256
+    const float* a0p = sA + (lane & 31) * lda + 4 * kh;
+    const float* a1p = a0p + 32 * lda;
+    float4 b0 = wp[0];
+    float4 b1 = wp[KB > 1 ? 256 : 0];
+#pragma unroll 4
+    for (int kb = 0; kb < KB; ++kb) {
+        const float4 b = b0;
+        b0 = b1;
+        if (kb + 2 < KB) b1 = wp[(kb + 2) * 256];
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc[1], 0, 0, 0);
+    }
 }
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][r] = 0.f;
+        acc[1][r] = 0.f;
+    }
+}
+
+// out[row][n] = act(acc + bias[n]) into an LDS tile (stride kLd)
+template <bool RELU>
+__device__ __forceinline__ void store_acc_lds(const f32x16 (&acc)[2], const float* __restrict__ bias, float* sOut,
+                                              int lane, int wave) {
+    const int n = wave * 32 + (lane & 31);
+    const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[m][r] + bn;
+            if (RELU) v = fmaxf(v, 0.f);
+            sOut[acc_row(m, r, lane) * kLd + n] = v;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------- TicTacToe
+struct TttDev {
+    const float* rep_conv;      // [9 taps][3][128] (Keras order)
+    const float* rep_conv_b;    // [128]
+    const float* rep_dense_p;   // packed [16][128][8]
+    const float* rep_dense_b;
+    const float* dyn_conv_p;    // [9 taps] x packed [16][128][8] (hidden channels 0..127)
+    const float* dyn_actbias;   // [9 actions][9 cells][128]: conv bias + sum of the action plane's valid taps
+    const float* dyn_dense_p;
+    const float* dyn_dense_b;
+    const float* dyn_reward_w;  // [1152]
+    const float* pred_conv_p;   // [9 cells] x packed [16][128][8]
+    const float* pred_conv_b;
+    const float* pred_dense_p;
+    const float* pred_dense_b;
+    const float* pred_value_w;  // [128]
+    const float* pred_policy_w; // [9][128]
+    const float* pred_policy_b; // [9]
+    float dyn_reward_b, pred_value_b;
+};
+
+__constant__ int kCellOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // heaviest (9 taps) first, corners (4 taps) last
+
+// Kernel A.  grid = 9 * ceil(B/64); block = 256.
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, const float* __restrict__ in_base,
+                                                            const int* __restrict__ parent_block, long block_stride,
+                                                            const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                            float* __restrict__ ppart, float* __restrict__ rpart) {
+    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
+    __shared__ long sRowOff[kRows];      // element offset of the row's input, -1 = skip
+    __shared__ int sAct[kRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + kRows - 1) / kRows;
+    const int cell = kCellOrder[blockIdx.x / nrb];
+    const int row0 = (blockIdx.x % nrb) * kRows;
+    const int ci = cell / 3, cj = cell % 3;
+
+    if (tid < kRows) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            if (INITIAL) {
+                off = (long)b * 27;
+            } else {
+                const int pb = parent_block ? parent_block[b] : 0;
+                if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
+                a = action[b];
+                if (a < 0 || a > 8) a = 0;
+            }
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+    float* sX = sBuf[0];
+    float* sH = sBuf[1];
+
+    if (INITIAL) {
+        // representation Conv2D 3x3 same, 3 -> 128, relu (games/tictactoe.py:182): K = 27, done on the VALU
+        float* sObs = sBuf[1];           // [64][27]
+        for (int i = tid; i < kRows * 27; i += kThreads) {
+            const int r = i / 27;
+            sObs[i] = sRowOff[r] >= 0 ? in_base[sRowOff[r] + (i % 27)] : 0.f;
+        }
+        __syncthreads();
+        const int n = tid & 127;
+        float wreg[27];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
+            const bool ok = ni >= 0 && ni < 3 && nj >= 0 && nj < 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) wreg[t * 3 + ch] = ok ? w.rep_conv[(t * 3 + ch) * 128 + n] : 0.f;
+        }
+        const float bn = w.rep_conv_b[n];
+        for (int r = tid >> 7; r < kRows; r += 2) {
+            float s = bn;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
+                if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) {
+                    const float* o = sObs + r * 27 + (ni * 3 + nj) * 3;
+                    s += o[0] * wreg[t * 3] + o[1] * wreg[t * 3 + 1] + o[2] * wreg[t * 3 + 2];
+                }
+            }
+            sX[r * kLd + n] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+    } else {
+        // dynamics Conv2D 3x3 same over [hidden(128) | one-hot action(9)] (games/tictactoe.py:189):
+        // sum over valid neighbour cells of hidden[cell'] @ W[tap][0:128]; the action planes are a bias.
+        unsigned tapmask = 0;                 // bit t set <=> tap t has an in-board source cell (wave-uniform)
+        for (int t = 0; t < 9; ++t) {
+            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
+            if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) tapmask |= 1u << t;
+        }
+        float4 stg[8];
+        auto issue = [&](int t) {
+            const int src_cell = (ci + t / 3 - 1) * 3 + (cj + t % 3 - 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+                const long off = sRowOff[r];
+                stg[i] = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + src_cell * 128 + c4 * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto commit = [&](float* buf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+                *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) = stg[i];
+            }
+        };
+        zero_acc(acc);
+        issue(__ffs(tapmask) - 1);
+        commit(sBuf[0]);
+        __syncthreads();
+        int buf = 0;
+#pragma unroll 1
+        while (tapmask) {
+            const int t = __ffs(tapmask) - 1;
+            tapmask &= tapmask - 1;
+            if (tapmask) issue(__ffs(tapmask) - 1);
+            gemm64<128>(sBuf[buf], kLd, w.dyn_conv_p + (size_t)t * 16384, acc, lane, wave);
+            if (tapmask) commit(sBuf[buf ^ 1]);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // + bias + action planes, relu -> sX
+        const int n = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(m, r, lane);
+                const float v = acc[m][r] + w.dyn_actbias[(sAct[row] * 9 + cell) * 128 + n];
+                sX[row * kLd + n] = fmaxf(v, 0.f);
+            }
+        __syncthreads();
+    }
+
+    // Dense 128 -> 128, relu = the new hidden state of this cell (games/tictactoe.py:184 / :191)
+    zero_acc(acc);
+    gemm64<128>(sX, kLd, INITIAL ? w.rep_dense_p : w.dyn_dense_p, acc, lane, wave);
+    {
+        const float* bias = INITIAL ? w.rep_dense_b : w.dyn_dense_b;
+        const int n = wave * 32 + (lane & 31);
+        const float bn = bias[n];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(m, r, lane);
+                const float v = fmaxf(acc[m][r] + bn, 0.f);
+                sH[row * kLd + n] = v;
+                if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;
+            }
+    }
+    __syncthreads();
+
+    if (!INITIAL) {
+        // reward head partial: Flatten(1152) . w restricted to this cell (games/tictactoe.py:193-195)
+        const int row = tid >> 2, q = tid & 3;
+        const float* wr = w.dyn_reward_w + cell * 128 + q * 32;
+        const float* h = sH + row * kLd + q * 32;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) s += h[j] * wr[j];
+        s += __shfl_xor(s, 1, 4);
+        s += __shfl_xor(s, 2, 4);
+        if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = s;
+    }
+
+    // prediction Conv2D 3x3 valid over the 3x3 board = sum over cells of hidden'[cell] @ W[cell]: this cell's term
+    zero_acc(acc);
+    gemm64<128>(sH, kLd, w.pred_conv_p + (size_t)cell * 16384, acc, lane, wave);
+    {
+        const int n = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(m, r, lane);
+                if (sRowOff[row] >= 0) ppart[((size_t)(row0 + row) * 9 + cell) * 128 + n] = acc[m][r];
+            }
+    }
+}
+
+// Kernel B.  grid = ceil(B/64).  parent_block only tells which rows are skipped.
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, const int* __restrict__ parent_block,
+                                                            const float* __restrict__ ppart, const float* __restrict__ rpart,
+                                                            float* __restrict__ out_reward, float* __restrict__ out_value,
+                                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
+    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * kRows;
+    float* sX = sBuf[0];
+    float* sH = sBuf[1];
+    {   // relu(sum of the nine per-cell partial products + bias) (games/tictactoe.py:201)
+        const int n = tid & 127;
+        const float bn = w.pred_conv_b[n];
+        for (int r = tid >> 7; r < kRows; r += 2) {
+            const int b = row0 + r;
+            float s = 0.f;
+            if (b < B) {
+                const float* p = ppart + (size_t)b * 9 * 128 + n;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) s += p[c * 128];
+            }
+            sX[r * kLd + n] = fmaxf(s + bn, 0.f);
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+    zero_acc(acc);
+    gemm64<128>(sX, kLd, w.pred_dense_p, acc, lane, wave);              // Dense 128 -> 128 relu (:204)
+    store_acc_lds<true>(acc, w.pred_dense_b, sH, lane, wave);
+    __syncthreads();
+    const int row = tid >> 2, q = tid & 3, b = row0 + row;
+    const bool live = b < B && (INITIAL || !parent_block || parent_block[b] >= 0);
+    const float* h = sH + row * kLd + q * 32;
+    // value head (tanh, :206) and the 9 policy logits (:208)
+#pragma unroll 1
+    for (int o = 0; o < 10; ++o) {
+        const float* wo = (o == 0 ? w.pred_value_w : w.pred_policy_w + (o - 1) * 128) + q * 32;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) s += h[j] * wo[j];
+        s += __shfl_xor(s, 1, 4);
+        s += __shfl_xor(s, 2, 4);
+        if (q == 0 && live) {
+            if (o == 0) {
+                const float v = tanhf(s + w.pred_value_b);
+                out_value[b] = v;                   // to_scalar is the identity: support_size None (config.py:28)
+                if (out_value_raw) out_value_raw[b] = v;
+            } else {
+                out_logits[(size_t)b * 9 + (o - 1)] = s + w.pred_policy_b[o - 1];
+            }
+        }
+    }
+    if (!INITIAL && q == 0 && live) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s += rpart[(size_t)b * 9 + c];
+        out_reward[b] = tanhf(s + w.dyn_reward_b);       // reward head, tanh (:194)
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- CartPole
+struct CartDev {
+    const float* rep_conv;      // [4 positions][101 bins][128] (Keras order)
+    const float* rep_conv_b;
+    const float* rep_dense_p;
+    const float* rep_dense_b;
+    const float* dyn_conv_p;    // packed [16][128][8]: taps of position 0 (the hidden row)
+    const float* dyn_conv_b;    // [128]
+    const float* dyn_plane;     // [128]: sum_k W[1][k][:], the all-ones action plane (network.py:88-104)
+    const float* dyn_dense_p;
+    const float* dyn_dense_b;
+    const float* dyn_rdense_p;
+    const float* dyn_rdense_b;
+    const float* dyn_reward_w;  // [128]
+    const float* pred_dense1_p;
+    const float* pred_dense1_b;
+    const float* pred_dense2_p;
+    const float* pred_dense2_b;
+    const float* pred_value_p;  // packed [16][128][8], columns >= 101 zero
+    const float* pred_value_b;  // [128], entries >= 101 zero
+    const float* pred_policy_w; // [2][128]
+    const float* pred_policy_b; // [2]
+    float dyn_reward_b;
+};
+
+// One launch per call; grid = ceil(B/64).
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, const float* __restrict__ in_base,
+                                                            const int* __restrict__ parent_block, long block_stride,
+                                                            const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                            float* __restrict__ out_reward, float* __restrict__ out_value,
+                                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
+    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
+    __shared__ long sRowOff[kRows];
+    __shared__ float sAct[kRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * kRows;
+    float* sX = sBuf[0];
+    float* sH = sBuf[1];
+    if (tid < kRows) {
+        const int b = row0 + tid;
+        long off = -1;
+        float a = 0.f;
+        if (b < B) {
+            if (INITIAL) {
+                off = (long)b * 4;
+            } else {
+                const int pb = parent_block ? parent_block[b] : 0;
+                if (pb >= 0) off = (long)pb * block_stride + (long)b * 128;
+                a = action[b] == 1 ? 1.f : 0.f;
+            }
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+    if (INITIAL) {
+        // scalar_to_support two-hot (utils.py:138-143, network.py:107-116) -> Conv1D k=4 valid 101 -> 128 relu
+        // (games/cartpole.py:98): only <= 8 of the 404 inputs are non-zero, gathered on the VALU.
+        const int n = tid & 127;
+        const float lo[4] = {-4.8f, -5.f, -0.418f, -5.f}, hi[4] = {4.8f, 5.f, 0.418f, 5.f};
+        const float bn = w.rep_conv_b[n];
+        for (int r = tid >> 7; r < kRows; r += 2) {
+            float s = bn;
+            if (sRowOff[r] >= 0) {
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const float x = (in_base[sRowOff[r] + pos] - lo[pos]) / (hi[pos] - lo[pos]);
+                    const float y = 100.f * (sqrtf(x + 1.f) - 1.f) / (sqrtf(2.f) - 1.f);
+                    const float fl = floorf(y);
+                    const float p = y - fl;
+                    const int il = (int)fl, ih = (int)ceilf(y);
+                    // tf.one_hot yields an all-zero row for an out-of-range index
+                    if (ih >= 0 && ih <= 100) s += p * w.rep_conv[(pos * 101 + ih) * 128 + n];
+                    if (il >= 0 && il <= 100) s += (1.f - p) * w.rep_conv[(pos * 101 + il) * 128 + n];
+                }
+            }
+            sX[r * kLd + n] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm64<128>(sX, kLd, w.rep_dense_p, acc, lane, wave);                 // Dense relu = hidden (:101)
+    } else {
+        // gather leaf.parent.hidden_state rows (agent.py:204) into LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            const long off = sRowOff[r];
+            const float4 v = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sH + r * kLd + c4 * 4) = v;
+        }
+        __syncthreads();
+        // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
+        zero_acc(acc);
+        gemm64<128>(sH, kLd, w.dyn_conv_p, acc, lane, wave);
+        const int n = wave * 32 + (lane & 31);
+        const float bn = w.dyn_conv_b[n], pn = w.dyn_plane[n];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(m, r, lane);
+                sX[row * kLd + n] = fmaxf(acc[m][r] + bn + sAct[row] * pn, 0.f);
+            }
+        __syncthreads();
+        zero_acc(acc);
+        gemm64<128>(sX, kLd, w.dyn_dense_p, acc, lane, wave);                 // Dense relu = hidden' (:108)
+    }
+    {   // hidden state out (both modes)
+        const float* bias = INITIAL ? w.rep_dense_b : w.dyn_dense_b;
+        const int n = wave * 32 + (lane & 31);
+        const float bn = bias[n];
+        __syncthreads();                       // RECURRENT: every wave is done reading sH (the gathered input)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(m, r, lane);
+                const float v = fmaxf(acc[m][r] + bn, 0.f);
+                sH[row * kLd + n] = v;
+                if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 128 + n] = v;
+            }
+    }
+    __syncthreads();
+    const int row = tid >> 2, q = tid & 3, b = row0 + row;
+    const bool live = sRowOff[row] >= 0;
+    if (!INITIAL) {
+        // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114)
+        zero_acc(acc);
+        gemm64<128>(sH, kLd, w.dyn_rdense_p, acc, lane, wave);
+        store_acc_lds<true>(acc, w.dyn_rdense_b, sX, lane, wave);
+        __syncthreads();
+        const float* h = sX + row * kLd + q * 32;
+        const float* wr = w.dyn_reward_w + q * 32;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) s += h[j] * wr[j];
+        s += __shfl_xor(s, 1, 4);
+        s += __shfl_xor(s, 2, 4);
+        if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        __syncthreads();
+    }
+    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124)
+    zero_acc(acc);
+    gemm64<128>(sH, kLd, w.pred_dense1_p, acc, lane, wave);
+    store_acc_lds<true>(acc, w.pred_dense1_b, sX, lane, wave);
+    __syncthreads();
+    zero_acc(acc);
+    gemm64<128>(sX, kLd, w.pred_dense2_p, acc, lane, wave);
+    __syncthreads();
+    store_acc_lds<true>(acc, w.pred_dense2_b, sH, lane, wave);
+    __syncthreads();
+    // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
+    zero_acc(acc);
+    gemm64<128>(sH, kLd, w.pred_value_p, acc, lane, wave);
+    store_acc_lds<false>(acc, w.pred_value_b, sX, lane, wave);
+    __syncthreads();
+    {
+        float* z = sX + row * kLd;
+        float mx = -INFINITY;
+        for (int j = q; j < 101; j += 4) mx = fmaxf(mx, z[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 4));
+        float den = 0.f;
+        for (int j = q; j < 101; j += 4) {
+            const float e = expf(z[j] - mx);
+            z[j] = e;
+            den += e;
+        }
+        den += __shfl_xor(den, 1, 4);
+        den += __shfl_xor(den, 2, 4);
+        float y = 0.f;
+        for (int j = q; j < 101; j += 4) {
+            const float pj = z[j] / den;
+            if (out_value_raw && live) out_value_raw[(size_t)b * 101 + j] = pj;
+            y += pj * (float)j;
+        }
+        y += __shfl_xor(y, 1, 4);
+        y += __shfl_xor(y, 2, 4);
+        if (q == 0 && live) {
+            y = y / 100.f;
+            const float t = (sqrtf(2.f) - 1.f) * y + 1.f;
+            out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
+        }
+        // policy logits: Dense 2 (:127)
+        const float* h = sH + row * kLd + q * 32;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float* wo = w.pred_policy_w + o * 128 + q * 32;
+            float s = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) s += h[j] * wo[j];
+            s += __shfl_xor(s, 1, 4);
+            s += __shfl_xor(s, 2, 4);
+            if (q == 0 && live) out_logits[(size_t)b * 2 + o] = s + w.pred_policy_b[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Packer {
+    std::vector<float> buf;
+    size_t add(const float* src, size_t n) {
+        const size_t off = buf.size();
+        buf.insert(buf.end(), src, src + n);
+        while (buf.size() % 4) buf.push_back(0.f);       // keep every table 16-B aligned
+        return off;
+    }
+    size_t add(const std::vector<float>& v) { return add(v.data(), v.size()); }
+    // W[K][N] row-major (N <= 128) -> Wp[K/8][128][8], missing columns zero
+    size_t add_packed(const float* W, int K, int N, int ldw) {
+        std::vector<float> p((size_t)K * 128, 0.f);
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < N; ++n) p[((size_t)(k / 8) * 128 + n) * 8 + (k % 8)] = W[(size_t)k * ldw + n];
+        return add(p);
+    }
+};
+
+constexpr int64_t kTttWeights = 3456 + 128 + 16384 + 128 + 157824 + 128 + 16384 + 128 + 1152 + 1 + 147456 + 128 + 16384 + 128 + 128 + 1 + 1152 + 9;
+constexpr int64_t kCartWeights = 51712 + 128 + 16384 + 128 + 32768 + 128 + 16384 + 128 + 16384 + 128 + 128 + 1 + 16384 + 128 + 16384 + 128 + 12928 + 101 + 256 + 2;
+
+}  // namespace
+
+struct mz_net {
+    int kind = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t training_steps = 0;
+    float* weights = nullptr;      // one device allocation holding every packed table
+    TttDev ttt{};
+    CartDev cart{};
+    float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
+    float* rpart = nullptr;        //                    [cap][9] reward partials
+    int scratch_cap = 0;
+};
+
+namespace {
+
+int ensure_scratch(mz_net* net, int batch) {
+    if (net->kind != MZ_NET_TICTACTOE || batch <= net->scratch_cap) return MZ_OK;
+    MZ_HIP(hipStreamSynchronize(net->stream));
+    if (net->ppart) (void)hipFree(net->ppart);
+    if (net->rpart) (void)hipFree(net->rpart);
+    net->ppart = net->rpart = nullptr;
+    net->scratch_cap = 0;
+    const int cap = (batch + kRows - 1) / kRows * kRows;
+    MZ_HIP(hipMalloc(reinterpret_cast<void**>(&net->ppart), (size_t)cap * 9 * 128 * sizeof(float)));
+    MZ_HIP(hipMalloc(reinterpret_cast<void**>(&net->rpart), (size_t)cap * 9 * sizeof(float)));
+    net->scratch_cap = cap;
+    return MZ_OK;
+}
+
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return MZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mz_net_num_weights(int32_t kind) {
+    return kind == MZ_NET_TICTACTOE ? kTttWeights : kind == MZ_NET_CARTPOLE ? kCartWeights : -1;
+}
+
+int32_t mz_net_hidden_size(int32_t kind) { return kind == MZ_NET_TICTACTOE ? 1152 : kind == MZ_NET_CARTPOLE ? 128 : -1; }
+
+int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t training_steps, void* stream,
+                  mz_net_t** out_net) {
+    MZ_REQUIRE(out_net != nullptr, "out_net is NULL");
+    *out_net = nullptr;
+    MZ_REQUIRE(kind == MZ_NET_TICTACTOE || kind == MZ_NET_CARTPOLE, "unknown network kind %d", kind);
+    MZ_REQUIRE(wh != nullptr, "weights_host is NULL");
+    MZ_REQUIRE(num_weights == mz_net_num_weights(kind), "network kind %d takes %lld weights, got %lld", kind,
+               (long long)mz_net_num_weights(kind), (long long)num_weights);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mz::fail(MZ_ERR_NO_DEVICE, "no HIP device visible: libmzhip has no CPU fallback");
+    }
+    mz_net* net = new (std::nothrow) mz_net();
+    if (!net) return mz::fail(MZ_ERR_OOM, "host allocation failed");
+    net->kind = kind;
+    net->stream = static_cast<hipStream_t>(stream);
+    net->training_steps = training_steps;
+    Packer pk;
+    std::vector<size_t> off;
+    const float* p = wh;
+    auto take = [&](size_t n) {
+        const float* q = p;
+        p += n;
+        return q;
+    };
+    if (kind == MZ_NET_TICTACTOE) {
+        const float* rep_conv = take(3456);
+        const float* rep_conv_b = take(128);
+        const float* rep_dense = take(16384);
+        const float* rep_dense_b = take(128);
+        const float* dyn_conv = take(157824);          // (3,3,137,128)
+        const float* dyn_conv_b = take(128);
+        const float* dyn_dense = take(16384);
+        const float* dyn_dense_b = take(128);
+        const float* dyn_reward = take(1152);
+        const float* dyn_reward_b = take(1);
+        const float* pred_conv = take(147456);         // (3,3,128,128)
+        const float* pred_conv_b = take(128);
+        const float* pred_dense = take(16384);
+        const float* pred_dense_b = take(128);
+        const float* pred_value = take(128);
+        const float* pred_value_b = take(1);
+        const float* pred_policy = take(1152);         // (128,9)
+        const float* pred_policy_b = take(9);
+        off.push_back(pk.add(rep_conv, 3456));                         // 0
+        off.push_back(pk.add(rep_conv_b, 128));                        // 1
+        off.push_back(pk.add_packed(rep_dense, 128, 128, 128));        // 2
+        off.push_back(pk.add(rep_dense_b, 128));                       // 3
+        size_t first = 0;
+        for (int t = 0; t < 9; ++t) {
+            const size_t o = pk.add_packed(dyn_conv + (size_t)t * 137 * 128, 128, 128, 128);
+            if (t == 0) first = o;
+        }
+        off.push_back(first);                                          // 4
+        std::vector<float> actbias(9 * 9 * 128);
+        for (int a = 0; a < 9; ++a)
+            for (int c = 0; c < 9; ++c)
+                for (int n = 0; n < 128; ++n) {
+                    double s = dyn_conv_b[n];
+                    for (int t = 0; t < 9; ++t) {
+                        const int ni = c / 3 + t / 3 - 1, nj = c % 3 + t % 3 - 1;
+                        if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) s += dyn_conv[((size_t)t * 137 + 128 + a) * 128 + n];
+                    }
+                    actbias[((size_t)a * 9 + c) * 128 + n] = (float)s;
+                }
+        off.push_back(pk.add(actbias));                                // 5
+        off.push_back(pk.add_packed(dyn_dense, 128, 128, 128));        // 6
+        off.push_back(pk.add(dyn_dense_b, 128));                       // 7
+        off.push_back(pk.add(dyn_reward, 1152));                       // 8
+        for (int c = 0; c < 9; ++c) {
+            const size_t o = pk.add_packed(pred_conv + (size_t)c * 128 * 128, 128, 128, 128);
+            if (c == 0) first = o;
+        }
+        off.push_back(first);                                          // 9
+        off.push_back(pk.add(pred_conv_b, 128));                       // 10
+        off.push_back(pk.add_packed(pred_dense, 128, 128, 128));       // 11
+        off.push_back(pk.add(pred_dense_b, 128));                      // 12
+        off.push_back(pk.add(pred_value, 128));                        // 13
+        std::vector<float> polT(9 * 128);
+        for (int k = 0; k < 128; ++k)
+            for (int o = 0; o < 9; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 9 + o];
+        off.push_back(pk.add(polT));                                   // 14
+        off.push_back(pk.add(pred_policy_b, 9));                       // 15
+        net->ttt.dyn_reward_b = dyn_reward_b[0];
+        net->ttt.pred_value_b = pred_value_b[0];
+    } else {
+        const float* rep_conv = take(51712);           // (4,101,128)
+        const float* rep_conv_b = take(128);
+        const float* rep_dense = take(16384);
+        const float* rep_dense_b = take(128);
+        const float* dyn_conv = take(32768);           // (2,128,128)
+        const float* dyn_conv_b = take(128);
+        const float* dyn_dense = take(16384);
+        const float* dyn_dense_b = take(128);
+        const float* dyn_rdense = take(16384);
+        const float* dyn_rdense_b = take(128);
+        const float* dyn_reward = take(128);
+        const float* dyn_reward_b = take(1);
+        const float* pred_dense1 = take(16384);
+        const float* pred_dense1_b = take(128);
+        const float* pred_dense2 = take(16384);
+        const float* pred_dense2_b = take(128);
+        const float* pred_value = take(12928);         // (128,101)
+        const float* pred_value_b = take(101);
+        const float* pred_policy = take(256);          // (128,2)
+        const float* pred_policy_b = take(2);
+        off.push_back(pk.add(rep_conv, 51712));                        // 0
+        off.push_back(pk.add(rep_conv_b, 128));                        // 1
+        off.push_back(pk.add_packed(rep_dense, 128, 128, 128));        // 2
+        off.push_back(pk.add(rep_dense_b, 128));                       // 3
+        off.push_back(pk.add_packed(dyn_conv, 128, 128, 128));         // 4
+        off.push_back(pk.add(dyn_conv_b, 128));                        // 5
+        std::vector<float> plane(128);
+        for (int n = 0; n < 128; ++n) {
+            double s = 0.0;
+            for (int k = 0; k < 128; ++k) s += dyn_conv[((size_t)128 + k) * 128 + n];
+            plane[n] = (float)s;
+        }
+        off.push_back(pk.add(plane));                                  // 6
+        off.push_back(pk.add_packed(dyn_dense, 128, 128, 128));        // 7
+        off.push_back(pk.add(dyn_dense_b, 128));                       // 8
+        off.push_back(pk.add_packed(dyn_rdense, 128, 128, 128));       // 9
+        off.push_back(pk.add(dyn_rdense_b, 128));                      // 10
+        off.push_back(pk.add(dyn_reward, 128));                        // 11
+        off.push_back(pk.add_packed(pred_dense1, 128, 128, 128));      // 12
+        off.push_back(pk.add(pred_dense1_b, 128));                     // 13
+        off.push_back(pk.add_packed(pred_dense2, 128, 128, 128));      // 14
+        off.push_back(pk.add(pred_dense2_b, 128));                     // 15
+        off.push_back(pk.add_packed(pred_value, 128, 101, 101));       // 16
+        std::vector<float> vb(128, 0.f);
+        for (int n = 0; n < 101; ++n) vb[n] = pred_value_b[n];
+        off.push_back(pk.add(vb));                                     // 17
+        std::vector<float> polT(2 * 128);
+        for (int k = 0; k < 128; ++k)
+            for (int o = 0; o < 2; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 2 + o];
+        off.push_back(pk.add(polT));                                   // 18
+        off.push_back(pk.add(pred_policy_b, 2));                       // 19
+        net->cart.dyn_reward_b = dyn_reward_b[0];
+    }
+    hipError_t e = hipGetDevice(&net->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&net->weights), pk.buf.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(net->weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (net->weights) (void)hipFree(net->weights);
+        delete net;
+        return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+    }
+    const float* d = net->weights;
+    if (kind == MZ_NET_TICTACTOE) {
+        TttDev& t = net->ttt;
+        t.rep_conv = d + off[0];
+        t.rep_conv_b = d + off[1];
+        t.rep_dense_p = d + off[2];
+        t.rep_dense_b = d + off[3];
+        t.dyn_conv_p = d + off[4];
+        t.dyn_actbias = d + off[5];
+        t.dyn_dense_p = d + off[6];
+        t.dyn_dense_b = d + off[7];
+        t.dyn_reward_w = d + off[8];
+        t.pred_conv_p = d + off[9];
+        t.pred_conv_b = d + off[10];
+        t.pred_dense_p = d + off[11];
+        t.pred_dense_b = d + off[12];
+        t.pred_value_w = d + off[13];
+        t.pred_policy_w = d + off[14];
+        t.pred_policy_b = d + off[15];
+    } else {
+        CartDev& c = net->cart;
+        c.rep_conv = d + off[0];
+        c.rep_conv_b = d + off[1];
+        c.rep_dense_p = d + off[2];
+        c.rep_dense_b = d + off[3];
+        c.dyn_conv_p = d + off[4];
+        c.dyn_conv_b = d + off[5];
+        c.dyn_plane = d + off[6];
+        c.dyn_dense_p = d + off[7];
+        c.dyn_dense_b = d + off[8];
+        c.dyn_rdense_p = d + off[9];
+        c.dyn_rdense_b = d + off[10];
+        c.dyn_reward_w = d + off[11];
+        c.pred_dense1_p = d + off[12];
+        c.pred_dense1_b = d + off[13];
+        c.pred_dense2_p = d + off[14];
+        c.pred_dense2_b = d + off[15];
+        c.pred_value_p = d + off[16];
+        c.pred_value_b = d + off[17];
+        c.pred_policy_w = d + off[18];
+        c.pred_policy_b = d + off[19];
+    }
+    *out_net = net;
+    return MZ_OK;
+}
+
+int mz_net_destroy(mz_net_t* net) {
+    if (!net) return MZ_OK;
+    (void)hipSetDevice(net->device);
+    (void)hipStreamSynchronize(net->stream);
+    if (net->weights) (void)hipFree(net->weights);
+    if (net->ppart) (void)hipFree(net->ppart);
+    if (net->rpart) (void)hipFree(net->rpart);
+    delete net;
+    return MZ_OK;
+}
+
+int mz_net_set_stream(mz_net_t* net, void* stream) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    net->stream = static_cast<hipStream_t>(stream);
+    return MZ_OK;
+}
+
+int64_t mz_net_training_steps(mz_net_t* net) { return net ? net->training_steps : -1; }
+
+int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
+                     float* out_logits, float* out_value_raw) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
+    if (batch == 0) return MZ_OK;
+    MZ_REQUIRE(observation && out_hidden && out_value && out_logits, "observation/out_hidden/out_value/out_logits is NULL");
+    MZ_HIP(hipSetDevice(net->device));
+    const int nrb = (batch + kRows - 1) / kRows;
+    if (net->kind == MZ_NET_TICTACTOE) {
+        int s = ensure_scratch(net, batch);
+        if (s != MZ_OK) return s;
+        ttt_cell_kernel<true><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
+                                                                    out_hidden, net->ppart, net->rpart);
+        ttt_head_kernel<true><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                                out_value, out_logits, out_value_raw);
+    } else {
+        cartpole_kernel<true><<<nrb, kThreads, 0, net->stream>>>(net->cart, batch, observation, nullptr, 0, nullptr,
+                                                               out_hidden, nullptr, out_value, out_logits, out_value_raw);
+    }
+    return launch_status("initial inference");
+}
+
+int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                       int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                       float* out_value, float* out_logits, float* out_value_raw) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
+    if (batch == 0) return MZ_OK;
+    MZ_REQUIRE(hidden_base && action && out_hidden && out_reward && out_value && out_logits,
+               "hidden_base/action/out_hidden/out_reward/out_value/out_logits is NULL");
+    MZ_REQUIRE(block_stride >= 0, "block_stride must be >= 0");
+    MZ_HIP(hipSetDevice(net->device));
+    const int nrb = (batch + kRows - 1) / kRows;
+    if (net->kind == MZ_NET_TICTACTOE) {
+        int s = ensure_scratch(net, batch);
+        if (s != MZ_OK) return s;
+        ttt_cell_kernel<false><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                     (long)block_stride, action, out_hidden, net->ppart,
+                                                                     net->rpart);
+        ttt_head_kernel<false><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                                 out_reward, out_value, out_logits, out_value_raw);
+    } else {
+        cartpole_kernel<false><<<nrb, kThreads, 0, net->stream>>>(net->cart, batch, hidden_base, parent_block,
+                                                                (long)block_stride, action, out_hidden, out_reward,
+                                                                out_value, out_logits, out_value_raw);
+    }
+    return launch_status("recurrent inference");
+}
+
+}  // extern "C"

@@ -1,0 +1,302 @@
+"""Network API of the reference (network.py:124-279) on top of the fused HIP inference kernels.
+
+`Network.initial_inference(observation)` and `Network.recurrent_inference(hidden_state, action)` return a
+`BatchNetworkOutput` with the reference's field names; tensors are torch tensors on the network's device
+(anything with `.numpy()`/indexing satisfies the reference's callers).  The value/reward scalarisation of
+`split_batch` (network.py:165-174) is fused into the kernels; the un-scalarised value head is still returned
+in `batch_value` so `value_to_scalar(batch_value)` gives the same numbers.
+
+Weights are one flat float32 buffer in Keras layer order (kernel, bias per layer; layout in DESIGN.md), the
+format `save`/`load` use (reference network.py:256-260 writes a TF checkpoint; TensorFlow is not available).
+"""
+import ctypes
+import math
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .exceptions import MuZeroError
+
+MZ_NET_TICTACTOE, MZ_NET_CARTPOLE = 1, 2
+
+
+def _to_numpy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class NetworkOutput:
+    """One game's network output (network.py:124-146)."""
+
+    def __init__(self, hidden_state, reward: Optional[float], value: float, policy_logits) -> None:
+        self.hidden_state = hidden_state
+        self.reward = reward
+        self.value = value
+        self.policy_logits = policy_logits
+
+    def __repr__(self) -> str:
+        return (f'NetworkOutput(hidden_state={self.hidden_state}, reward={self.reward}, value={self.value}, '
+                f'policy_logits={self.policy_logits})')
+
+    def masked_policy(self, actions: List[int]) -> np.ndarray:
+        """exp(logits) restricted to `actions`, normalised; float32, full length A (network.py:142-146)."""
+        logits = _to_numpy(self.policy_logits).astype(np.float32)
+        mask = np.zeros_like(logits)
+        mask[list(actions)] = 1
+        weights = np.exp(logits) * mask
+        return weights / weights.sum()
+
+
+class BatchNetworkOutput:
+    """network.py:149-174.  `batch_value_scalar` / `batch_reward_scalar` hold the kernel-fused to_scalar results."""
+
+    def __init__(self, batch_hidden_state, batch_reward, batch_value, batch_policy_logits,
+                 reward_to_scalar: Callable, value_to_scalar: Callable,
+                 batch_value_scalar=None, batch_reward_scalar=None) -> None:
+        self.batch_hidden_state = batch_hidden_state
+        self.batch_reward = batch_reward
+        self.batch_value = batch_value
+        self.batch_policy_logits = batch_policy_logits
+        self.reward_to_scalar = reward_to_scalar
+        self.value_to_scalar = value_to_scalar
+        self.batch_value_scalar = batch_value_scalar
+        self.batch_reward_scalar = batch_reward_scalar
+
+    def value_scalars(self):
+        if self.batch_value_scalar is not None:
+            return self.batch_value_scalar
+        v = self.value_to_scalar(self.batch_value)
+        return v.reshape(v.shape[0])
+
+    def reward_scalars(self):
+        if self.batch_reward is None and self.batch_reward_scalar is None:
+            return None
+        if self.batch_reward_scalar is not None:
+            return self.batch_reward_scalar
+        r = self.reward_to_scalar(self.batch_reward)
+        return r.reshape(r.shape[0])
+
+    def split_batch(self) -> List[NetworkOutput]:
+        values = _to_numpy(self.value_scalars()).reshape(-1)
+        rewards = self.reward_scalars()
+        rewards = None if rewards is None else _to_numpy(rewards).reshape(-1)
+        return [NetworkOutput(hidden_state=self.batch_hidden_state[i],
+                              reward=None if rewards is None else float(rewards[i]),
+                              value=float(values[i]),
+                              policy_logits=self.batch_policy_logits[i])
+                for i in range(len(values))]
+
+
+def glorot_uniform_weights(spec, seed: int) -> np.ndarray:
+    """Keras defaults (glorot-uniform kernels, zero biases) for a [(name, shape)] spec -> flat float32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    for name, shape in spec:
+        if name.endswith('_k'):
+            receptive = int(np.prod(shape[:-2]))
+            limit = math.sqrt(6.0 / (receptive * shape[-2] + receptive * shape[-1]))
+            parts.append(rng.uniform(-limit, limit, size=shape).astype(np.float32).ravel())
+        else:
+            parts.append(np.zeros(int(np.prod(shape)), np.float32))
+    return np.concatenate(parts)
+
+
+class Network:
+    """Base class of the HIP-backed networks (reference network.py:177-279).
+
+    Sub-classes set KIND, WEIGHT_SPEC, OBSERVATION_SHAPE, HIDDEN_SHAPE, ACTION_SPACE_SIZE, VALUE_RAW.
+    """
+    KIND = 0
+    WEIGHT_SPEC = []
+    OBSERVATION_SHAPE = ()
+    HIDDEN_SHAPE = ()
+    ACTION_SPACE_SIZE = 0
+    VALUE_RAW = 1          # width of the un-scalarised value head
+
+    def __init__(self, config, weights: Optional[np.ndarray] = None, seed: int = 0, training_steps: int = 0,
+                 device='cuda', **_unused_reference_parameters) -> None:
+        self.config = config
+        self._h = None
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise MuZeroError('Network needs a HIP device (torch.cuda.is_available() is False); '
+                              'muzero_amd has no CPU fallback')
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.hidden_size = int(np.prod(self.HIDDEN_SHAPE))
+        self.observation_size = int(np.prod(self.OBSERVATION_SHAPE))
+        self.steps = int(training_steps)
+        self._stream = None
+        self.set_weights(glorot_uniform_weights(self.WEIGHT_SPEC, seed) if weights is None else weights,
+                         training_steps)
+
+    # ------------------------------------------------------------------ weights
+    @classmethod
+    def num_weights(cls) -> int:
+        return sum(int(np.prod(shape)) for _, shape in cls.WEIGHT_SPEC)
+
+    def set_weights(self, flat: np.ndarray, training_steps: Optional[int] = None) -> None:
+        """Upload a new flat weight buffer (the weight hand-off of training.py:62-68 / network.py:256-266)."""
+        flat = np.ascontiguousarray(flat, np.float32).ravel()
+        if flat.size != self.num_weights():
+            raise MuZeroError(f'{type(self).__name__} takes {self.num_weights()} weights, got {flat.size}')
+        if training_steps is not None:
+            self.steps = int(training_steps)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.mz_net_create(self.KIND, flat.ctypes.data, flat.size, self.steps,
+                                               ctypes.c_void_p(self._stream), ctypes.byref(handle)))
+        self.close()
+        self._h = handle
+        self._weights = flat.copy()
+
+    def get_weights(self) -> np.ndarray:
+        return self._weights.copy()
+
+    def training_steps(self) -> int:
+        return self.steps
+
+    def save(self, checkpoint_prefix: str) -> None:
+        np.savez(checkpoint_prefix + '.npz', weights=self._weights, steps=np.int64(self.steps),
+                 kind=np.int32(self.KIND))
+
+    def load(self, checkpoint_prefix: str) -> None:
+        with np.load(checkpoint_prefix + '.npz', allow_pickle=False) as data:
+            if int(data['kind']) != self.KIND:
+                raise MuZeroError('checkpoint is for a different network kind')
+            self.set_weights(data['weights'], int(data['steps']))
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mz_net_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self) -> str:
+        return f'{type(self).__name__}(parameters={self.num_weights()}, training_steps={self.steps})'
+
+    # ------------------------------------------------------------------ inference
+    def _sync_stream(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            _lib.check(self._lib.mz_net_set_stream(self._h, ctypes.c_void_p(stream)))
+            self._stream = stream
+
+    def _as_f32(self, x, width):
+        t = torch.as_tensor(x if isinstance(x, torch.Tensor) else np.asarray(x), device=self.device)
+        t = t.to(torch.float32).reshape(-1, width).contiguous()
+        return t
+
+    def _outputs(self, batch, with_reward):
+        f32 = dict(dtype=torch.float32, device=self.device)
+        return dict(hidden=torch.empty(batch, self.hidden_size, **f32),
+                    reward=torch.empty(batch, **f32) if with_reward else None,
+                    value=torch.empty(batch, **f32), logits=torch.empty(batch, self.ACTION_SPACE_SIZE, **f32),
+                    raw=torch.empty(batch, self.VALUE_RAW, **f32))
+
+    def _wrap(self, out):
+        return BatchNetworkOutput(
+            batch_hidden_state=out['hidden'].view(-1, *self.HIDDEN_SHAPE),
+            batch_reward=None if out['reward'] is None else out['reward'].view(-1, 1),
+            batch_value=out['raw'], batch_policy_logits=out['logits'],
+            reward_to_scalar=self.config.reward_config.to_scalar if self.config is not None else (lambda t: t),
+            value_to_scalar=self.config.value_config.to_scalar if self.config is not None else (lambda t: t),
+            batch_value_scalar=out['value'], batch_reward_scalar=out['reward'])
+
+    def initial_inference(self, observation) -> BatchNetworkOutput:
+        """network.py:221-229.  observation: [B, *OBSERVATION_SHAPE]."""
+        self._sync_stream()
+        obs = self._as_f32(observation, self.observation_size)
+        out = self._outputs(obs.shape[0], with_reward=False)
+        _lib.check(self._lib.mz_infer_initial(self._h, obs.shape[0], obs.data_ptr(), out['hidden'].data_ptr(),
+                                              out['value'].data_ptr(), out['logits'].data_ptr(),
+                                              out['raw'].data_ptr()))
+        return self._wrap(out)
+
+    def recurrent_inference(self, hidden_state, action) -> BatchNetworkOutput:
+        """network.py:246-254.  hidden_state: [B, *HIDDEN_SHAPE]; action: [B] ints."""
+        self._sync_stream()
+        hid = self._as_f32(hidden_state, self.hidden_size)
+        act = torch.as_tensor(action if isinstance(action, torch.Tensor) else np.asarray(action),
+                              device=self.device).to(torch.int32).reshape(-1).contiguous()
+        if act.shape[0] != hid.shape[0]:
+            raise MuZeroError(f'batch mismatch: {hid.shape[0]} hidden states, {act.shape[0]} actions')
+        out = self._outputs(hid.shape[0], with_reward=True)
+        _lib.check(self._lib.mz_infer_recurrent(self._h, hid.shape[0], hid.data_ptr(), None, 0, act.data_ptr(),
+                                                out['hidden'].data_ptr(), out['reward'].data_ptr(),
+                                                out['value'].data_ptr(), out['logits'].data_ptr(),
+                                                out['raw'].data_ptr()))
+        return self._wrap(out)
+
+    def recurrent_inference_pool(self, hidden_pool, parent_block, action, out_block, reward, value, logits):
+        """The lockstep fast path: gather leaf.parent.hidden_state rows of `hidden_pool` [N+1,T,H] by
+        `parent_block` inside the kernel (agent.py:204) and write the new hidden states straight into
+        hidden_pool[out_block]; reward/value/logits are caller-owned [T]/[T]/[T,A] f32 outputs."""
+        self._sync_stream()
+        n_blocks, T, H = hidden_pool.shape
+        if H != self.hidden_size or not hidden_pool.is_contiguous() or hidden_pool.dtype != torch.float32:
+            raise MuZeroError(f'hidden_pool must be a contiguous float32 [blocks, T, {self.hidden_size}] tensor')
+        if not 0 <= out_block < n_blocks:
+            raise MuZeroError(f'out_block {out_block} outside [0, {n_blocks})')
+        for name, t, dt, shape in (('parent_block', parent_block, torch.int32, (T,)), ('action', action, torch.int32, (T,)),
+                                   ('reward', reward, torch.float32, (T,)), ('value', value, torch.float32, (T,)),
+                                   ('logits', logits, torch.float32, (T, self.ACTION_SPACE_SIZE))):
+            if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous() or t.device != hidden_pool.device:
+                raise MuZeroError(f'{name}: expected contiguous {dt} {shape} on {hidden_pool.device}')
+        _lib.check(self._lib.mz_infer_recurrent(self._h, T, hidden_pool.data_ptr(), parent_block.data_ptr(), T * H,
+                                                action.data_ptr(), hidden_pool[out_block].data_ptr(),
+                                                reward.data_ptr(), value.data_ptr(), logits.data_ptr(), None))
+
+    def initial_inference_pool(self, observation, hidden_pool, value, logits):
+        """initial_inference writing the root hidden states into hidden_pool[0]."""
+        self._sync_stream()
+        obs = self._as_f32(observation, self.observation_size)
+        if obs.shape[0] != hidden_pool.shape[1]:
+            raise MuZeroError('observation batch does not match the pool')
+        _lib.check(self._lib.mz_infer_initial(self._h, obs.shape[0], obs.data_ptr(), hidden_pool[0].data_ptr(),
+                                              value.data_ptr(), logits.data_ptr(), None))
+
+
+def _spec(kind):
+    # kept in one place: the same tables the oracle uses are restated here so the product never imports oracle/
+    if kind == 'tictactoe':      # reference games/tictactoe.py:179-213
+        return [('rep_conv_k', (3, 3, 3, 128)), ('rep_conv_b', (128,)), ('rep_dense_k', (128, 128)), ('rep_dense_b', (128,)),
+                ('dyn_conv_k', (3, 3, 137, 128)), ('dyn_conv_b', (128,)), ('dyn_dense_k', (128, 128)), ('dyn_dense_b', (128,)),
+                ('dyn_reward_k', (1152, 1)), ('dyn_reward_b', (1,)),
+                ('pred_conv_k', (3, 3, 128, 128)), ('pred_conv_b', (128,)), ('pred_dense_k', (128, 128)), ('pred_dense_b', (128,)),
+                ('pred_value_k', (128, 1)), ('pred_value_b', (1,)), ('pred_policy_k', (128, 9)), ('pred_policy_b', (9,))]
+    if kind == 'cartpole':       # reference games/cartpole.py:92-132
+        return [('rep_conv_k', (4, 101, 128)), ('rep_conv_b', (128,)), ('rep_dense_k', (128, 128)), ('rep_dense_b', (128,)),
+                ('dyn_conv_k', (2, 128, 128)), ('dyn_conv_b', (128,)), ('dyn_dense_k', (128, 128)), ('dyn_dense_b', (128,)),
+                ('dyn_rdense_k', (128, 128)), ('dyn_rdense_b', (128,)), ('dyn_reward_k', (128, 1)), ('dyn_reward_b', (1,)),
+                ('pred_dense1_k', (128, 128)), ('pred_dense1_b', (128,)), ('pred_dense2_k', (128, 128)), ('pred_dense2_b', (128,)),
+                ('pred_value_k', (128, 101)), ('pred_value_b', (101,)), ('pred_policy_k', (128, 2)), ('pred_policy_b', (2,))]
+    raise MuZeroError(f'unknown network kind {kind}')
+
+
+class TicTacToeNetwork(Network):
+    """games/tictactoe.py:151-220: observation (3,3,3), hidden (3,3,128), tanh value/reward, 9 logits."""
+    KIND = MZ_NET_TICTACTOE
+    WEIGHT_SPEC = _spec('tictactoe')
+    OBSERVATION_SHAPE = (3, 3, 3)
+    HIDDEN_SHAPE = (3, 3, 128)
+    ACTION_SPACE_SIZE = 9
+    VALUE_RAW = 1
+
+
+class CartPoleNetwork(Network):
+    """games/cartpole.py:63-139: observation (4,), hidden (1,128), 101-bin value support, sigmoid reward."""
+    KIND = MZ_NET_CARTPOLE
+    WEIGHT_SPEC = _spec('cartpole')
+    OBSERVATION_SHAPE = (4,)
+    HIDDEN_SHAPE = (1, 128)
+    ACTION_SPACE_SIZE = 2
+    VALUE_RAW = 101

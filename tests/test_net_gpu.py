@@ -1,0 +1,131 @@
+"""Fused HIP inference kernels (through the C ABI) against the fp64 numpy oracle.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative for fp32.  Stated here as rtol=1e-5 plus atol=1e-5 x the
+head's output scale (1 for tanh/sigmoid/logit heads and hidden activations, 100 for CartPole's value range).
+The oracle itself is "parity unpinned" against TensorFlow (oracle/net_oracle.py header)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import net_oracle as no
+
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def make(kind, seed=11):
+    from muzero_amd.network import CartPoleNetwork, TicTacToeNetwork
+    flat = no.random_weights(kind, seed)
+    cls = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork}[kind]
+    return cls(config=None, weights=flat), no.make_oracle(kind, flat)
+
+
+def observations(kind, B, rng):
+    if kind == 'tictactoe':
+        board = rng.integers(-1, 2, size=(B, 3, 3))
+        to_play = rng.integers(0, 2, size=(B, 1, 1))
+        obs = np.stack([(board == 0), (board == 1), np.broadcast_to(to_play, (B, 3, 3))], -1).astype(np.float32)
+        return obs.reshape(B, 27)
+    span = np.array([2.4, 3.0, 0.21, 3.0], np.float32)
+    return (rng.uniform(-1, 1, size=(B, 4)) * span).astype(np.float32)
+
+
+def close(got, want, scale=1.0):
+    np.testing.assert_allclose(got.detach().cpu().numpy().reshape(np.shape(want)), want, rtol=RTOL, atol=ATOL * scale)
+
+
+@pytest.mark.parametrize('B', [1, 63, 64, 65, 200])
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
+def test_initial_and_recurrent_inference(kind, B):
+    net, ref = make(kind)
+    rng = np.random.default_rng(B)
+    vscale = 100.0 if kind == 'cartpole' else 1.0
+    obs = observations(kind, B, rng)
+    out = net.initial_inference(obs)
+    h, v, logits, raw = ref.initial_inference(obs)
+    close(out.batch_hidden_state, h)
+    close(out.batch_value_scalar, v, vscale)
+    close(out.batch_policy_logits, logits)
+    close(out.batch_value, raw)
+    assert out.batch_reward is None
+    # value_to_scalar(batch_value) on the host gives the same scalars as the fused epilogue
+    action = rng.integers(0, ref.A, size=B)
+    out2 = net.recurrent_inference(out.batch_hidden_state, action)
+    h2, r2, v2, l2, raw2 = ref.recurrent_inference(h, action)
+    close(out2.batch_hidden_state, h2)
+    close(out2.batch_reward_scalar, r2)
+    close(out2.batch_value_scalar, v2, vscale)
+    close(out2.batch_policy_logits, l2)
+    close(out2.batch_value, raw2)
+    # a second unrolled step, from the kernel's own hidden state
+    action3 = rng.integers(0, ref.A, size=B)
+    out3 = net.recurrent_inference(out2.batch_hidden_state, action3)
+    h3, r3, v3, l3, _ = ref.recurrent_inference(h2, action3)
+    close(out3.batch_hidden_state, h3)
+    close(out3.batch_reward_scalar, r3)
+    close(out3.batch_value_scalar, v3, vscale)
+    close(out3.batch_policy_logits, l3)
+    outs = out2.split_batch()
+    assert len(outs) == B and isinstance(outs[0].value, float) and isinstance(outs[0].reward, float)
+    assert outs[B - 1].value == float(out2.batch_value_scalar[B - 1])
+
+
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
+def test_pool_gather_path_and_inactive_rows(kind):
+    """recurrent_inference reading leaf.parent.hidden_state rows by parent block from the [N+1][T][H] tensor and
+    writing block 3 in place; rows with parent_block < 0 are left untouched."""
+    import torch
+    net, ref = make(kind, seed=5)
+    T, H, A = 150, ref.H, ref.A
+    rng = np.random.default_rng(3)
+    pool_np = np.abs(rng.standard_normal((4, T, H))).astype(np.float32)
+    pool_np[3] = -7.0                                      # sentinel in the output block
+    parent = rng.integers(-1, 3, size=T).astype(np.int32)
+    action = rng.integers(0, A, size=T).astype(np.int32)
+    pool = torch.from_numpy(pool_np).cuda()
+    reward = torch.full((T,), -7.0, device='cuda')
+    value = torch.full((T,), -7.0, device='cuda')
+    logits = torch.full((T, A), -7.0, device='cuda')
+    net.recurrent_inference_pool(pool, torch.from_numpy(parent).cuda(), torch.from_numpy(action).cuda(), 3, reward,
+                                 value, logits)
+    live = parent >= 0
+    gathered = pool_np[np.maximum(parent, 0), np.arange(T)]
+    h2, r2, v2, l2, _ = ref.recurrent_inference(gathered[live], action[live])
+    got = pool[3].cpu().numpy()
+    np.testing.assert_allclose(got[live], h2, rtol=RTOL, atol=ATOL)
+    assert (got[~live] == -7.0).all()
+    np.testing.assert_allclose(reward.cpu().numpy()[live], r2, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(value.cpu().numpy()[live], v2, rtol=RTOL, atol=ATOL * (100 if kind == 'cartpole' else 1))
+    np.testing.assert_allclose(logits.cpu().numpy()[live], l2, rtol=RTOL, atol=ATOL)
+    assert (reward.cpu().numpy()[~live] == -7.0).all() and (logits.cpu().numpy()[~live] == -7.0).all()
+    np.testing.assert_array_equal(pool[:3].cpu().numpy(), pool_np[:3])          # inputs untouched
+
+
+def test_host_to_scalar_matches_fused_epilogue():
+    """ScalarConfig.to_scalar (config.py:25-40) applied on the host to the raw 101-bin head equals the fused one."""
+    from muzero_amd.config import ScalarConfig
+    from muzero_amd.utils import KnownBounds
+    net, _ = make('cartpole')
+    out = net.initial_inference(observations('cartpole', 40, np.random.default_rng(0)))
+    cfg = ScalarConfig(known_bounds=KnownBounds(0.0, 100.0), support_size=100)
+    np.testing.assert_allclose(cfg.to_scalar(out.batch_value).cpu().numpy(), out.batch_value_scalar.cpu().numpy(),
+                               rtol=1e-5, atol=1e-3)
+
+
+def test_weight_count_and_checkpoint_round_trip(tmp_path):
+    from muzero_amd.exceptions import MuZeroError
+    from muzero_amd.network import CartPoleNetwork, TicTacToeNetwork
+    assert TicTacToeNetwork.num_weights() == no.num_weights('tictactoe')
+    assert CartPoleNetwork.num_weights() == no.num_weights('cartpole')
+    net, _ = make('tictactoe')
+    obs = observations('tictactoe', 8, np.random.default_rng(1))
+    before = net.initial_inference(obs).batch_policy_logits.cpu().numpy()
+    net.steps = 1234
+    net.save(str(tmp_path / 'ckpt'))
+    other = TicTacToeNetwork(config=None, seed=99)
+    assert other.training_steps() == 0
+    other.load(str(tmp_path / 'ckpt'))
+    assert other.training_steps() == 1234
+    np.testing.assert_array_equal(other.initial_inference(obs).batch_policy_logits.cpu().numpy(), before)
+    with pytest.raises(MuZeroError):
+        TicTacToeNetwork(config=None, weights=np.zeros(10, np.float32))
