@@ -65,7 +65,9 @@ def synthetic_outputs(T, A, N, seed, reward, device):
 
 
 class SyntheticTreeMove:
-    """One move of T searches with injected outputs (tree kernels only)."""
+    """One move of T searches with injected outputs (tree kernels only; workloads without a reference network)."""
+    dominant = 'step_kernel'
+    bound = 'hbm'
 
     def __init__(self, wl, device, seed):
         from muzero_amd.tree_pool import TreePool
@@ -77,8 +79,6 @@ class SyntheticTreeMove:
             wl['T'], wl['A'], wl['N'], seed, wl['reward'], device)
         self.temperature = torch.ones(wl['T'], dtype=torch.float64, device=device)
         self.events = []
-
-    dominant = 'step_kernel'
 
     def run(self, timed_events=False):
         pool, N = self.pool, self.wl['N']
@@ -99,35 +99,179 @@ class SyntheticTreeMove:
         action = pool.select_action(self.u, self.temperature)
         return stats, action
 
-    def flops_per_launch(self):
-        return None
+
+class HipEvents:
+    """Raw HIP events (hipEventCreate/Record/ElapsedTime through ctypes) recorded on torch's current stream --
+    the stream every muzero_amd launch goes to -- so they bracket exactly the launches of the timed region."""
+    _hip = None
+
+    def __init__(self):
+        import ctypes
+        if HipEvents._hip is None:
+            HipEvents._hip = ctypes.CDLL('libamdhip64.so')
+        self.ct, self.hip = ctypes, HipEvents._hip
+        self.free, self.used = [], []
+
+    def new(self):
+        if self.free:
+            ev = self.free.pop()
+        else:
+            ev = self.ct.c_void_p()
+            rc = self.hip.hipEventCreate(self.ct.byref(ev))
+            assert rc == 0, f'hipEventCreate -> {rc}'
+        self.used.append(ev)
+        return ev
+
+    def record(self, ev=None):
+        ev = ev if ev is not None else self.new()
+        stream = self.ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.hip.hipEventRecord(ev, stream)
+        assert rc == 0, f'hipEventRecord -> {rc}'
+        return ev
+
+    def elapsed_ms(self, a, b):
+        ms = self.ct.c_float()
+        rc = self.hip.hipEventElapsedTime(self.ct.byref(ms), a, b)
+        assert rc == 0, f'hipEventElapsedTime -> {rc}'
+        return ms.value
 
 
-def cpu_baseline_tree(wl, seconds):
-    """The CPU oracle (oracle/mcts_oracle.py, a port of the reference's Python MCTS) on ONE host core, same
-    shapes and synthetic outputs, for about `seconds` of CPU work.  Tree-only: an upper bound on the
-    reference, whose real path adds a batch-1 TensorFlow call per simulation."""
-    from oracle import mcts_oracle
+class _InferenceEvents:
+    """Per recurrent_inference call of the timed region: event before, event between the two launches (recorded by
+    the library, mz_net_set_mid_event), event after, event after the tree step."""
+
+    def __init__(self, net, two_launches):
+        self.ev = HipEvents()
+        self.net, self.two = net, two_launches
+        self.calls, self.on = [], False
+
+    def before_inference(self, s):
+        if self.on:
+            self._cur = [self.ev.record(), None, None, None]
+            if self.two:
+                self._cur[1] = self.ev.new()
+                self.net._lib.mz_net_set_mid_event(self.net._h, self._cur[1])
+
+    def after_inference(self, s):
+        if self.on:
+            self._cur[2] = self.ev.record()
+
+    def after_tree(self, s):
+        if self.on:
+            self._cur[3] = self.ev.record()
+            self.calls.append(self._cur)
+
+    def stop(self):
+        self.on = False
+        if self.two:
+            self.net._lib.mz_net_set_mid_event(self.net._h, None)
+
+    def durations(self):
+        """-> (first kernel s, second kernel s, tree step s), each averaged over the timed region"""
+        first, second, tree = [], [], []
+        for e0, em, e1, e2 in self.calls:
+            if em is not None:
+                first.append(self.ev.elapsed_ms(e0, em))
+                second.append(self.ev.elapsed_ms(em, e1))
+            else:
+                first.append(self.ev.elapsed_ms(e0, e1))
+            tree.append(self.ev.elapsed_ms(e1, e2))
+        mean = lambda v: float(np.mean(v)) * 1e-3 if v else None
+        return mean(first), mean(second), mean(tree)
+
+
+class NetworkMove:
+    """One move of T games with the HIP network in the loop (muzero_amd.selfplay.LockstepSearch): the full
+    reference path of MCTSAgent.make_move, batched."""
+    bound = 'mfma'
+
+    def __init__(self, wl, device, seed, world):
+        from muzero_amd.games import cartpole, tictactoe
+        from muzero_amd.selfplay import LockstepSearch, TrajectoryGather
+        mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[wl['net']]
+        self.wl = wl
+        self.config = mod.make_config(num_simulations=wl['N'])
+        self.net = self.config.network_config.network_class(self.config, seed=7)       # random-init (glorot) weights
+        self.search = LockstepSearch(self.config, self.net, num_trees=wl['T'], device=device)
+        self.pool = self.search.pool
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        T, A = wl['T'], wl['A']
+        if wl['net'] == 'tictactoe':     # random mid-game boards: planes [X, O, to_play]
+            cells = torch.randint(0, 3, (T, 9), generator=g, device=device)
+            to_play = torch.randint(0, 2, (T, 1), generator=g, device=device).expand(T, 9)
+            self.obs = torch.stack([(cells == 0), (cells == 1), to_play.bool()], -1).float().reshape(T, 27).contiguous()
+            self.dominant = 'ttt_cell_kernel<recurrent>'
+            # SURVEY.md 8(d) terms this kernel covers per evaluation: conv 49*137*128, dense 9*128*128,
+            # reward 1152, prediction conv 9*128*128 (multiply-adds x2)
+            self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
+        else:
+            span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
+            self.obs = ((torch.rand(T, 4, generator=g, device=device) * 2 - 1) * span).contiguous()
+            self.dominant = 'cartpole_kernel<recurrent>'
+            self.flops_per_eval = 223232
+        self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
+        self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
+        self.temperature = torch.ones(T, dtype=torch.float64, device=device)
+        self.hooks = _InferenceEvents(self.net, two_launches=(wl['net'] == 'tictactoe'))
+        self.gather = TrajectoryGather(T, A, device) if world > 1 else None
+
+    def run(self, timed_events=False):
+        self.hooks.on = timed_events
+        visits, root_value, minmax, policy, action = self.search.run(self.obs, self.noise, self.u, self.temperature,
+                                                                     hooks=self.hooks)
+        if self.gather is not None:      # the one exchange step: search statistics of this move to every rank
+            self.gather.start(policy, root_value, action)
+        return visits, action
+
+    def finish(self):
+        if self.gather is not None:
+            self.gather.wait()
+
+
+def cpu_baseline(wl, seconds):
+    """The CPU oracle -- a port of the reference's Python MCTS (oracle/mcts_oracle.py) calling the numpy network
+    port (oracle/net_oracle.py, float32, batch 1 per simulation like agent.py:204-207) -- on ONE host core, same
+    shapes, for about `seconds` of CPU work.  Workloads without a network time the tree alone."""
+    from oracle import mcts_oracle, net_oracle
     A, N = wl['A'], wl['N']
     rng = np.random.Generator(np.random.PCG64(99))
+    net = None
+    if wl['net']:
+        net = net_oracle.make_oracle(wl['net'], net_oracle.random_weights(wl['net'], 7), dtype=np.float32)
     sims, moves = 0, 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        logits = rng.standard_normal((N + 1, A)).astype(np.float32)
-        values = np.tanh(rng.standard_normal(N + 1)).astype(np.float32)
-        rewards = rng.random(N + 1).astype(np.float32)
         tree = mcts_oracle.TreeOracle(A, N, wl['players'], wl['discount'], wl['default'], wl['bounds'])
-        tree.expand_root(mcts_oracle.masked_policy_f32(logits[0], range(A)), range(A))
+        if net is not None:
+            if wl['net'] == 'tictactoe':
+                obs = rng.integers(0, 2, size=(1, 27)).astype(np.float32)
+            else:
+                obs = (rng.uniform(-1, 1, size=(1, 4)) * [2.4, 3.0, 0.21, 3.0]).astype(np.float32)
+            hidden, _, logits, _ = net.initial_inference(obs)
+            hiddens = [hidden]
+            tree.expand_root(mcts_oracle.masked_policy_f32(logits[0], range(A)), range(A))
+        else:
+            logits = rng.standard_normal((N + 1, A)).astype(np.float32)
+            values = np.tanh(rng.standard_normal(N + 1)).astype(np.float32)
+            rewards = rng.random(N + 1).astype(np.float32)
+            tree.expand_root(mcts_oracle.masked_policy_f32(logits[0], range(A)), range(A))
         tree.add_root_noise(rng.dirichlet([1.0] * A), 0.25)
         for s in range(N):
-            tree.select()
-            tree.expand_backprop(mcts_oracle.masked_policy_f32(logits[s + 1], range(A)), rewards[s + 1], values[s + 1])
+            parent, action = tree.select()
+            if net is not None:
+                h, r, v, lg, _ = net.recurrent_inference(hiddens[parent], np.array([action]))
+                hiddens.append(h)
+                tree.expand_backprop(mcts_oracle.masked_policy_f32(lg[0], range(A)), r[0], v[0])
+            else:
+                tree.expand_backprop(mcts_oracle.masked_policy_f32(logits[s + 1], range(A)), rewards[s + 1], values[s + 1])
         tree.select_action(float(rng.random()), 1.0)
         sims += N
         moves += 1
     dt = time.perf_counter() - t0
+    what = 'python tree oracle + numpy fp32 network oracle at batch 1' if net is not None else 'python tree oracle only'
     return dict(value=sims / dt, unit='simulations/s', cores=1, kind='port',
-                sample=f'{moves} single-tree moves x {N} simulations, A={A}, python oracle (tree only), {dt:.1f} s')
+                sample=f'{moves} single-game moves x {N} simulations, A={A}, {what}, {dt:.1f} s')
 
 
 def main():
@@ -137,7 +281,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='tictactoe_4096x25', choices=sorted(WORKLOADS))
     ap.add_argument('--trees', type=int, default=None, help='override trees per GPU (profiling only)')
-    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -156,10 +301,14 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.trees:
         wl['T'] = args.trees
-    move = SyntheticTreeMove(wl, device, seed=1234 + rank)      # per-rank seeds: ranks search different games
+    with_net = wl['net'] is not None and not args.inject
+    # per-rank seeds: every rank searches different games
+    move = NetworkMove(wl, device, 1234 + rank, world) if with_net else SyntheticTreeMove(wl, device, 1234 + rank)
 
     for _ in range(args.warmup):
         move.run()
+    if with_net:
+        move.finish()
     torch.cuda.synchronize()
     c0 = move.pool.counters()
     if world > 1:
@@ -168,6 +317,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         move.run(timed_events=True)
+    if with_net:
+        move.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,29 +334,45 @@ def main():
     sum_d = int(c1[1] - c0[1])
     assert sims_rank == args.steps * wl['T'] * wl['N'], (sims_rank, args.steps, wl['T'], wl['N'])
     total_sims = sims_rank * world
-    kernel_ms = [a.elapsed_time(b) for a, b in move.events]
-    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-    # algorithmic bytes of one dominant-kernel launch: T simulations with the measured mean path length
     mean_d = sum_d / sims_rank
-    bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
-    achieved = bytes_launch / avg_kernel_s / 1e9
+    tree_bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
+    extra = {}
+    if with_net:
+        move.hooks.stop()
+        k1, k2, tree_s = move.hooks.durations()
+        flops_launch = wl['T'] * move.flops_per_eval
+        achieved = flops_launch / k1 / 1e12
+        roofline = {'bound': 'mfma', 'kernel': move.dominant, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch}
+        extra = {'second_inference_kernel_us': None if k2 is None else k2 * 1e6, 'tree_step_kernel_us': tree_s * 1e6,
+                 'tree_step_GBps': tree_bytes_launch / tree_s / 1e9, 'mean_path_len': mean_d,
+                 'recurrent_inference_evals_per_sec': total_sims / elapsed}
+        network = f"{wl['net']} network, random-init weights, fp32 MFMA"
+    else:
+        ms = [a.elapsed_time(b) for a, b in move.events]
+        avg = float(np.mean(ms)) * 1e-3
+        achieved = tree_bytes_launch / avg / 1e9
+        roofline = {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_us': avg * 1e6,
+                    'bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d}
+        network = 'injected outputs (tree kernels only)'
 
     if rank == 0:
         out = {
             'metric': 'mcts_simulations_per_sec', 'value': total_sims / elapsed, 'unit': 'simulations/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if with_net else 'f64',
             'data': 'synthetic',
             'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'actions': wl['A'],
-                       'simulations_per_move': wl['N'], 'network': 'injected outputs (tree kernels only)',
-                       'sharding': f'{world} x independent game shards, no collective'},
-            'roofline': {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'avg_launch_us': avg_kernel_s * 1e6, 'bytes_per_launch': bytes_launch,
-                         'mean_path_len': mean_d},
+                       'simulations_per_move': wl['N'], 'network': network,
+                       'sharding': f'{world} independent game shards (one rank per GPU)' +
+                                   (', per-move all-gather of search statistics' if world > 1 and with_net else '')},
+            'roofline': roofline,
         }
+        out.update(extra)
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_tree(wl, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(wl if with_net else dict(wl, net=None), args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

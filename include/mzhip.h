@@ -166,6 +166,10 @@ int mz_net_create(int32_t kind, const float* weights_host, int64_t num_weights, 
 int mz_net_destroy(mz_net_t* net);
 int mz_net_set_stream(mz_net_t* net, void* stream);
 int64_t mz_net_training_steps(mz_net_t* net);
+/* Measurement hook (no counterpart in the reference): when hip_event (a hipEvent_t) is non-NULL, every later
+ * inference call that consists of two launches (TicTacToe: per-cell kernel, then head kernel) records it on the
+ * stream between them, so a caller bracketing the call with its own events can time each kernel. NULL disables. */
+int mz_net_set_mid_event(mz_net_t* net, void* hip_event);
 
 /* Network.initial_inference (network.py:221-229) fused with split_batch's to_scalar (network.py:165-174).
  *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4);

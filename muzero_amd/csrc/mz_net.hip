@@ -582,6 +582,7 @@ struct mz_net {
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
+    hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
 };
 
 namespace {
@@ -829,6 +830,12 @@ int mz_net_set_stream(mz_net_t* net, void* stream) {
 
 int64_t mz_net_training_steps(mz_net_t* net) { return net ? net->training_steps : -1; }
 
+int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    net->mid_event = static_cast<hipEvent_t>(hip_event);
+    return MZ_OK;
+}
+
 int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
                      float* out_logits, float* out_value_raw) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
@@ -842,6 +849,7 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
         if (s != MZ_OK) return s;
         ttt_cell_kernel<true><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
                                                                     out_hidden, net->ppart, net->rpart);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
         ttt_head_kernel<true><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
                                                                 out_value, out_logits, out_value_raw);
     } else {
@@ -868,6 +876,7 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
         ttt_cell_kernel<false><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, hidden_base, parent_block,
                                                                      (long)block_stride, action, out_hidden, net->ppart,
                                                                      net->rpart);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
         ttt_head_kernel<false><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
                                                                  out_reward, out_value, out_logits, out_value_raw);
     } else {

@@ -1,0 +1,105 @@
+"""Lockstep search over T concurrent games: the batched form of MCTSAgent.make_move (agent.py:219-232).
+
+One `LockstepSearch.run()` is one move of every game:
+
+    initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand ->
+    backprop) -> root statistics -> action sampling
+
+Every stage is a HIP launch on one stream; nothing returns to the host inside a move.  Hidden states live in
+one [N+1][T][H] tensor: simulation s writes block s+1 of every tree (lockstep), and the inference kernel
+gathers leaf.parent.hidden_state rows by the parent block that select reports, so there is no gather or
+scatter copy (agent.py:204 is an operand load).
+
+Games shard over GPUs as independent ranks (one process per GPU); the only exchange is `TrajectoryGather`,
+an all-gather of each move's search statistics (root visit distribution, root value, chosen action) -- what the
+reference's agents send to the replay buffer (agent.py:231, agent_services.py:54).
+"""
+from typing import Optional
+
+import torch
+
+from .exceptions import MuZeroError
+from .tree_pool import TreePool
+
+
+class LockstepSearch:
+    def __init__(self, config, network, num_trees: int, device=None):
+        self.config = config
+        self.network = network
+        g, m = config.game_config, config.mcts_config
+        kb = config.value_config.known_bounds
+        self.device = torch.device(device) if device is not None else network.device
+        self.T, self.A, self.N = int(num_trees), g.action_space_size, m.num_simulations
+        if network.ACTION_SPACE_SIZE != self.A:
+            raise MuZeroError(f'network has {network.ACTION_SPACE_SIZE} actions, the game {self.A}')
+        self.pool = TreePool(num_trees=self.T, num_actions=self.A, max_simulations=self.N,
+                             num_players=g.num_players, discount=g.discount, default_value=m.default_value,
+                             known_bounds=None if kb is None else kb.endpoints(), device=self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.hidden = torch.empty(self.N + 1, self.T, network.hidden_size, **f32)
+        self.root_value_net = torch.empty(self.T, **f32)        # initial-inference value (unused by the search)
+        self.logits = torch.empty(self.T, self.A, **f32)
+        self.reward = torch.empty(self.T, **f32)
+        self.value = torch.empty(self.T, **f32)
+        self.frac = m.root_exploration_fraction
+
+    def run(self, observation, noise, u, temperature, legal=None, n_legal=None, hooks=None):
+        """One move for all T games.  observation [T, obs] f32; noise [T,A] f64 (Dirichlet draws, injected like
+        np.random.dirichlet in agent.py:172); u [T] f64 uniforms; temperature [T] f64.
+        Returns (visits [T,A] i32, root_value [T] f64, minmax [T,2] f64, policy [T,A] f32, action [T] i32)."""
+        pool, net, N = self.pool, self.network, self.N
+        pool.reset()
+        net.initial_inference_pool(observation, self.hidden, self.root_value_net, self.logits)
+        pool.expand_roots(self.logits, legal, n_legal, logits=True)
+        pool.add_root_noise(noise, self.frac)
+        parent, action = pool.select()
+        for s in range(N):
+            if hooks is not None:
+                hooks.before_inference(s)
+            net.recurrent_inference_pool(self.hidden, parent, action, s + 1, self.reward, self.value, self.logits)
+            if hooks is not None:
+                hooks.after_inference(s)
+            if s + 1 < N:
+                parent, action = pool.step(self.logits, self.reward, self.value, logits=True)
+            else:
+                pool.expand_backprop(self.logits, self.reward, self.value, logits=True)
+            if hooks is not None:
+                hooks.after_tree(s)
+        visits, root_value, minmax, policy = pool.root_stats()
+        chosen = pool.select_action(u, temperature)
+        return visits, root_value, minmax, policy, chosen
+
+
+class TrajectoryGather:
+    """All-gather of per-move search statistics over the ranks (RCCL over xGMI on GPUs, gloo in CPU tests).
+
+    Record per game: policy[A] f32 | root_value f32 | action f32 -> [T, A+2] f32 per rank, gathered into
+    [world, T, A+2].  The payload is KBs per move, so the call is latency-bound; it is issued asynchronously and
+    waited for one move later."""
+
+    def __init__(self, num_trees: int, num_actions: int, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.T, self.A = num_trees, num_actions
+        self.send = torch.empty(num_trees, num_actions + 2, dtype=torch.float32, device=device)
+        self.recv = torch.empty(self.world, num_trees, num_actions + 2, dtype=torch.float32, device=device)
+        self.work = None
+
+    def start(self, policy, root_value, action):
+        self.wait()
+        self.send[:, :self.A] = policy
+        self.send[:, self.A] = root_value.to(torch.float32)
+        self.send[:, self.A + 1] = action.to(torch.float32)
+        if self.world == 1:
+            self.recv[0].copy_(self.send)
+            return
+        self.work = self.dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group,
+                                                     async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.recv

@@ -1,0 +1,215 @@
+"""End-to-end self-play path on the GPU: lockstep search with the HIP network in the loop, and the drop-in
+single-game MCTSAgent replaying a full game of the reference agent (tests/golden/ttt_game_*.npz)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GAME_FIXTURES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class Recorder:
+    """Copies the per-simulation network outputs and the select results out of a LockstepSearch run."""
+
+    def __init__(self, search):
+        self.s = search
+        self.parent, self.action, self.reward, self.value, self.logits = [], [], [], [], []
+
+    def before_inference(self, s):
+        self.parent.append(self.s.pool._parent.clone())
+        self.action.append(self.s.pool._action.clone())
+
+    def after_inference(self, s):
+        self.reward.append(self.s.reward.clone())
+        self.value.append(self.s.value.clone())
+        self.logits.append(self.s.logits.clone())
+
+    def after_tree(self, s):
+        pass
+
+
+@pytest.mark.parametrize('game', ['tictactoe', 'cartpole'])
+def test_lockstep_search_with_network_in_the_loop(game):
+    import torch
+    from muzero_amd.games import cartpole, tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import c_oracle, net_oracle
+    mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[game]
+    N, T = 12, 70
+    config = mod.make_config(num_simulations=N)
+    flat = net_oracle.random_weights(game, 21)
+    net = config.network_config.network_class(config, weights=flat)
+    ref = net_oracle.make_oracle(game, flat)
+    A, H = ref.A, ref.H
+    rng = np.random.default_rng(5)
+    if game == 'tictactoe':
+        obs = rng.integers(0, 2, size=(T, 27)).astype(np.float32)
+    else:
+        obs = (rng.uniform(-1, 1, size=(T, 4)) * [2.4, 3, 0.2, 3]).astype(np.float32)
+    n_legal = rng.integers(0, A + 1, size=T).astype(np.int32)            # ragged, some trees inactive
+    n_legal[0] = A
+    legal = np.zeros((T, A), np.int32)
+    for t in range(T):
+        legal[t, :n_legal[t]] = np.sort(rng.permutation(A)[:n_legal[t]])
+    noise = np.zeros((T, A))
+    for t in range(T):
+        if n_legal[t]:
+            noise[t, :n_legal[t]] = rng.dirichlet([1.0] * int(n_legal[t]))
+    u = rng.random(T)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    search = LockstepSearch(config, net, num_trees=T)
+    rec = Recorder(search)
+    visits, root_value, minmax, policy, chosen = search.run(dev(obs), dev(noise), dev(u), dev(np.ones(T)), dev(legal),
+                                                            dev(n_legal), hooks=rec)
+    live = n_legal > 0
+    assert (visits.cpu().numpy()[live].sum(1) == N).all() and (visits.cpu().numpy()[~live] == 0).all()
+    # (1) wiring: every simulation's hidden state / outputs are the oracle network applied to the parent's row
+    hidden = search.hidden.cpu().numpy()
+    vscale = 100.0 if game == 'cartpole' else 1.0
+    h0, _, l0, _ = ref.initial_inference(obs)
+    np.testing.assert_allclose(hidden[0], h0, rtol=1e-5, atol=1e-5)
+    for s in range(N):
+        pb, act = rec.parent[s].cpu().numpy(), rec.action[s].cpu().numpy()
+        assert (pb[live] >= 0).all() and (pb[live] <= s).all() and (pb[~live] == -1).all()
+        h2, r2, v2, l2, _ = ref.recurrent_inference(hidden[pb[live], np.nonzero(live)[0]], act[live])
+        np.testing.assert_allclose(hidden[s + 1][live], h2, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(rec.reward[s].cpu().numpy()[live], r2, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(rec.value[s].cpu().numpy()[live], v2, rtol=1e-5, atol=1e-5 * vscale)
+        np.testing.assert_allclose(rec.logits[s].cpu().numpy()[live], l2, rtol=1e-5, atol=1e-5)
+    # (3) tree statistics: replay the device's own outputs (and the priors it derived from the logits) through the
+    # C oracle -> identical selections, visit counts, root values and chosen actions
+    kb = config.value_config.known_bounds
+    opool = c_oracle.OraclePool(T, A, N, config.game_config.num_players, config.game_config.discount,
+                                config.mcts_config.default_value, None if kb is None else kb.endpoints())
+    priors = np.zeros((N + 1, T, A), np.float32)
+    for t in np.nonzero(live)[0]:
+        for e in range(N + 1):
+            p = search.pool.read_block(int(t), e)['prior']
+            priors[e, t, :len(p)] = p if e else 0
+    # root priors were noise-mixed on the device; rebuild the pre-noise fp32 priors from the logits path instead
+    root = np.zeros((T, A), np.float32)
+    root_logits = l0.astype(np.float32)
+    for t in np.nonzero(live)[0]:
+        acts = legal[t, :n_legal[t]]
+        m = np.zeros(A, np.float32)
+        m[acts] = np.exp(root_logits[t, acts])
+        root[t] = m / m.sum()
+    opool.expand_roots(root, legal, n_legal)
+    opool.add_root_noise(noise, config.mcts_config.root_exploration_fraction)
+    mism = 0
+    for s in range(N):
+        p, a = opool.select()
+        mism += int((p != rec.parent[s].cpu().numpy()).sum() + (a != rec.action[s].cpu().numpy()).sum())
+        opool.expand_backprop(priors[s + 1], rec.reward[s].cpu().numpy(), rec.value[s].cpu().numpy())
+    # the root priors come from two different exp implementations (<= 2 ulp apart, trap T4): allow a vanishing
+    # number of near-tie divergences there, none is expected in practice
+    assert mism <= 2, mism
+    if mism == 0:
+        v2, rv2, mm2, pol2 = opool.root_stats()
+        np.testing.assert_array_equal(visits.cpu().numpy(), v2)
+        np.testing.assert_allclose(root_value.cpu().numpy()[live], rv2[live], rtol=1e-12)
+        np.testing.assert_array_equal(chosen.cpu().numpy(), opool.select_action(u, 1.0))
+
+
+class FixtureOutput:
+    """NetworkOutput whose masked_policy returns the priors the reference computed for this call (trap T4)."""
+
+    def __init__(self, hidden_state, reward, value, policy_logits, priors):
+        self.hidden_state, self.reward, self.value, self.policy_logits, self._priors = (
+            hidden_state, reward, value, policy_logits, priors)
+
+    def masked_policy(self, actions):
+        return self._priors
+
+
+class FixtureBatch:
+    def __init__(self, out):
+        self._out = out
+
+    def split_batch(self):
+        return [self._out]
+
+
+class ReplayNetwork:
+    """Duck-typed network (agent.py:141) replaying the outputs the reference agent was given."""
+
+    def __init__(self, fx):
+        self.fx, self.calls, self.trace = fx, 0, []
+
+    def training_steps(self):
+        return 0
+
+    def _next(self, with_reward):
+        i = self.calls
+        self.calls += 1
+        fx = self.fx
+        return FixtureBatch(FixtureOutput(np.full((1,), float(i), np.float32),
+                                          float(fx['rewards'][i]) if with_reward else None, float(fx['values'][i]),
+                                          fx['logits'][i], fx['priors'][i]))
+
+    def initial_inference(self, observation):
+        self.trace.append(np.asarray(observation)[0].copy())
+        return self._next(False)
+
+    def recurrent_inference(self, hidden_state, action):
+        return self._next(True)
+
+
+@pytest.mark.parametrize('name', GAME_FIXTURES)
+def test_dropin_agent_replays_a_reference_game(name):
+    """MCTSAgent.play_game on the TicTacToe environment reproduces the reference agent's whole game: same host
+    RNG seeds, same network outputs -> same actions, root values (bit-exact fp64) and policy targets."""
+    from muzero_amd.agent import MCTSAgent
+    from muzero_amd.environment import TicTacToeEnvironment
+    from muzero_amd.games import tictactoe
+    fx = load_golden(name)
+    seed = int(name.split('_s')[-1])
+    config = tictactoe.make_config(num_simulations=int(fx['N']))
+    net = ReplayNetwork(fx)
+    agent = MCTSAgent(config=config, network=net, agent_id='golden', device='cuda')
+    random.seed(seed)
+    np.random.seed(seed)
+    history = agent.play_game(TicTacToeEnvironment())
+    assert len(history) == int(fx['moves']) and net.calls == int(fx['calls'])
+    np.testing.assert_array_equal(np.array(history.actions), fx['actions'])
+    np.testing.assert_array_equal(np.array(history.rewards, np.float64), fx['env_rewards'])
+    np.testing.assert_array_equal(np.array(history.root_values, np.float64), fx['root_values'])
+    np.testing.assert_array_equal(np.stack([np.asarray(p) for p in history.policies]), fx['policies'])
+    np.testing.assert_array_equal(np.stack([np.asarray(o) for o in history.observations]), fx['observations'])
+    np.testing.assert_array_equal(np.array(history.to_plays), fx['to_plays'])
+    np.testing.assert_array_equal(np.stack(net.trace), fx['initial_observations'])
+    assert history.metadata['agent_id'] == 'golden' and history.metadata['network_id'] == '0'
+
+
+def test_dropin_agent_stepwise_api():
+    """The reference's step-by-step methods (select_leaf / expand_node / backpropagate, ucb_score, Node views)."""
+    from muzero_amd.agent import MCTSAgent
+    from muzero_amd.games import tictactoe
+    from muzero_amd.utils import MinMaxStats
+    fx = load_golden('ttt_legal_s2')
+    config = tictactoe.make_config(num_simulations=int(fx['N']))
+    agent = MCTSAgent(config=config, network=ReplayNetwork(fx), device='cuda')
+    net = agent.network
+    np.random.seed(0)
+    root = agent.new_root()
+    mm = MinMaxStats(config.value_config.known_bounds)
+    legal = [int(a) for a in fx['legal']]
+    agent.expand_node(root, legal, net.initial_inference(np.zeros((1, 27), np.float32)).split_batch()[0])
+    assert root.expanded() and list(root.children) == legal
+    from muzero_amd.tree_pool import torch
+    agent._pool.add_root_noise(torch.from_numpy(fx['noise'].reshape(1, 9)).cuda(), float(fx['frac']))
+    for s in range(int(fx['N'])):
+        host_action, _ = agent.select_child(root, mm)          # host re-evaluation of the same rule
+        action, leaf = agent.select_leaf(root, mm)
+        assert action == int(fx['trace_action'][s]) and leaf.parent._block == int(fx['trace_parent'][s])
+        if leaf.parent is root:
+            assert host_action == action
+        assert not leaf.expanded() and leaf.visit_count == 0 and np.isnan(leaf.value)
+        out = net.recurrent_inference(None, None).split_batch()[0]
+        agent.expand_node(leaf, config.action_space(), out)
+        agent.backpropagate(leaf, out.value, mm)
+        assert leaf.expanded() and leaf.visit_count == 1 and leaf.reward == float(np.float32(out.reward))
+    assert root.visit_count == int(fx['N']) and root.value == float(fx['root_value'])
+    np.testing.assert_array_equal([root.children[a].visit_count for a in legal], fx['root_visits'][legal])
