@@ -25,6 +25,7 @@
 //   softmax over the 101-bin value support and support_to_scalar fused in the epilogue.
 #include "mz_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -34,63 +35,88 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kThreads = 256;
-constexpr int kRows = 64;          // games per workgroup tile
 constexpr int kLd = 132;           // LDS row stride in floats for K = 128 (33 16-B slots: odd -> conflict-free)
 
-// C/D element (m-tile m, register r) of a 32x32x2 accumulator held by lane `lane`: row within the 64-row tile
+// C/D element (m-tile m, register r) of a 32x32x2 accumulator held by lane `lane`: row within the tile
 __device__ __forceinline__ int acc_row(int m, int r, int lane) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// acc[2] += sA[64][K] (LDS, stride lda) * W[K][128], W packed as Wp[K/8][128][8]; this wave: columns 32*wave..+31.
-template <int K>
-__device__ __forceinline__ void gemm64(const float* sA, int lda, const float* __restrict__ Wp, f32x16 (&acc)[2],
-                                       int lane, int wave) {
-    constexpr int KB = K / 8;
-    const int n = wave * 32 + (lane & 31), kh = lane >> 5;
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + n * 2 + kh;      // + kb * 256
-    const float* a0p = sA + (lane & 31) * lda + 4 * kh;
-    const float* a1p = a0p + 32 * lda;
-    float4 b0 = wp[0];
-    float4 b1 = wp[KB > 1 ? 256 : 0];
-#pragma unroll 4
-    for (int kb = 0; kb < KB; ++kb) {
-        const float4 b = b0;
-        b0 = b1;
-        if (kb + 2 < KB) b1 = wp[(kb + 2) * 256];
-        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
-        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc[1], 0, 0, 0);
+// The whole [128][32-column] weight slice of one wave for one GEMM stage, in registers (64 VGPRs).  It is loaded
+// one stage AHEAD (during the previous stage's MFMAs), so no MFMA ever waits on a weight load, and -- vmcnt
+// being in-order -- the activation-tile gather issued after it gets a whole stage to land as well.
+struct BFrag {
+    float4 v[16];
+};
+
+// W packed as Wp[K/8 = 16][128][8]: lane (n = 32*wave + lane%32, kh = lane/32) takes k = 8*kb + 4*kh .. +3
+__device__ __forceinline__ void load_b(BFrag& b, const float* __restrict__ Wp, int lane, int wave) {
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + (wave * 32 + (lane & 31)) * 2 + (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) b.v[kb] = wp[kb * 256];
+}
+
+// acc[MT] += sA[32*MT][128] (LDS, stride kLd) * W[128][this wave's 32 columns] held in b.
+template <int MT>
+__device__ __forceinline__ void mma_tile(const float* sA, const BFrag& b, f32x16 (&acc)[MT], int lane) {
+    const float* ap = sA + (lane & 31) * kLd + 4 * (lane >> 5);
+    float4 a[MT], an[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4*>(ap + m * 32 * kLd);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        if (kb + 1 < 16) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const float4*>(ap + m * 32 * kLd + (kb + 1) * 8);
+        }
+        const float4 bv = b.v[kb];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bv.x, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bv.y, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bv.z, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bv.w, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = an[m];
     }
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2]) {
+template <int MT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc[0][r] = 0.f;
-        acc[1][r] = 0.f;
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 }
 
 // out[row][n] = act(acc + bias[n]) into an LDS tile (stride kLd)
-template <bool RELU>
-__device__ __forceinline__ void store_acc_lds(const f32x16 (&acc)[2], const float* __restrict__ bias, float* sOut,
+template <int MT, bool RELU>
+__device__ __forceinline__ void store_acc_lds(const f32x16 (&acc)[MT], const float* __restrict__ bias, float* sOut,
                                               int lane, int wave) {
     const int n = wave * 32 + (lane & 31);
     const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[m][r] + bn;
             if (RELU) v = fmaxf(v, 0.f);
             sOut[acc_row(m, r, lane) * kLd + n] = v;
         }
+}
+
+// dot of a 32-float slice of an LDS row with a 32-float slice of weights, then summed over the 4 threads of a row
+__device__ __forceinline__ float dot32x4(const float* h, const float* wv) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(h + j);
+        const float4 b = *reinterpret_cast<const float4*>(wv + j);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s += __shfl_xor(s, 1, 4);
+    s += __shfl_xor(s, 2, 4);
+    return s;
 }
 
 // ----------------------------------------------------------------------------------------------- TicTacToe
@@ -116,22 +142,38 @@ struct TttDev {
 
 __constant__ int kCellOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // heaviest (9 taps) first, corners (4 taps) last
 
-// Kernel A.  grid = 9 * ceil(B/64); block = 256.
-template <bool INITIAL>
+// Kernel A.  grid = 9 * ceil(B / (32*MT)); block = 256.
+template <bool INITIAL, int MT>
 __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, const float* __restrict__ in_base,
                                                             const int* __restrict__ parent_block, long block_stride,
                                                             const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                            float* __restrict__ ppart, float* __restrict__ rpart) {
-    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
-    __shared__ long sRowOff[kRows];      // element offset of the row's input, -1 = skip
-    __shared__ int sAct[kRows];
+                                                            float* __restrict__ ppart, float* __restrict__ rpart,
+                                                            int order, long long* __restrict__ trace) {
+    constexpr int ROWS = 32 * MT;
+    constexpr int NSTG = MT * 4;                     // float4 staging loads per thread per tile
+    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
+    __shared__ long sRowOff[ROWS];                   // element offset of the row's input, -1 = skip
+    __shared__ int sAct[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + kRows - 1) / kRows;
-    const int cell = kCellOrder[blockIdx.x / nrb];
-    const int row0 = (blockIdx.x % nrb) * kRows;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int cell = order == 0 ? kCellOrder[blockIdx.x / nrb] : (int)(blockIdx.x % 9);
+    const int row0 = (order == 0 ? blockIdx.x % nrb : blockIdx.x / 9) * ROWS;
     const int ci = cell / 3, cj = cell % 3;
 
-    if (tid < kRows) {
+    BFrag bcur, bnext;
+    unsigned tapmask = 0;                            // bit t set <=> tap t has an in-board source cell (uniform)
+    if (INITIAL) {
+        load_b(bcur, w.rep_dense_p, lane, wave);
+    } else {
+        for (int t = 0; t < 9; ++t) {
+            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
+            if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) tapmask |= 1u << t;
+        }
+        load_b(bcur, w.dyn_conv_p + (size_t)(__ffs(tapmask) - 1) * 16384, lane, wave);
+    }
+
+    if (tid < ROWS) {
         const int b = row0 + tid;
         long off = -1;
         int a = 0;
@@ -150,14 +192,14 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
     }
     __syncthreads();
 
-    f32x16 acc[2];
+    f32x16 acc[MT];
     float* sX = sBuf[0];
     float* sH = sBuf[1];
 
     if (INITIAL) {
         // representation Conv2D 3x3 same, 3 -> 128, relu (games/tictactoe.py:182): K = 27, done on the VALU
-        float* sObs = sBuf[1];           // [64][27]
-        for (int i = tid; i < kRows * 27; i += kThreads) {
+        float* sObs = sBuf[1];           // [ROWS][27]
+        for (int i = tid; i < ROWS * 27; i += kThreads) {
             const int r = i / 27;
             sObs[i] = sRowOff[r] >= 0 ? in_base[sRowOff[r] + (i % 27)] : 0.f;
         }
@@ -172,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
             for (int ch = 0; ch < 3; ++ch) wreg[t * 3 + ch] = ok ? w.rep_conv[(t * 3 + ch) * 128 + n] : 0.f;
         }
         const float bn = w.rep_conv_b[n];
-        for (int r = tid >> 7; r < kRows; r += 2) {
+        for (int r = tid >> 7; r < ROWS; r += 2) {
             float s = bn;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -184,31 +226,34 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
             }
             sX[r * kLd + n] = fmaxf(s, 0.f);
         }
+        load_b(bnext, w.pred_conv_p + (size_t)cell * 16384, lane, wave);
         __syncthreads();
     } else {
         // dynamics Conv2D 3x3 same over [hidden(128) | one-hot action(9)] (games/tictactoe.py:189):
         // sum over valid neighbour cells of hidden[cell'] @ W[tap][0:128]; the action planes are a bias.
-        unsigned tapmask = 0;                 // bit t set <=> tap t has an in-board source cell (wave-uniform)
-        for (int t = 0; t < 9; ++t) {
-            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
-            if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) tapmask |= 1u << t;
-        }
-        float4 stg[8];
-        auto issue = [&](int t) {
-            const int src_cell = (ci + t / 3 - 1) * 3 + (cj + t % 3 - 1);
+        // Per-thread gather addresses of the activation tile, resolved once (branch-free loads afterwards).
+        const float* sptr[NSTG];
+        unsigned svalid = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-                const long off = sRowOff[r];
-                stg[i] = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + src_cell * 128 + c4 * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int i = 0; i < NSTG; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            const long off = sRowOff[r];
+            sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
+            if (off >= 0) svalid |= 1u << i;
+        }
+        float4 stg[NSTG];
+        auto issue = [&](int t) {
+            const int src = ((ci + t / 3 - 1) * 3 + (cj + t % 3 - 1)) * 128;
+#pragma unroll
+            for (int i = 0; i < NSTG; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src);
         };
         auto commit = [&](float* buf) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NSTG; ++i) {
                 const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-                *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) = stg[i];
+                const bool ok = (svalid >> i) & 1u;          // component-wise selects: keeps stg[] in registers
+                *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
+                    make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
             }
         };
         zero_acc(acc);
@@ -218,18 +263,23 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
         int buf = 0;
 #pragma unroll 1
         while (tapmask) {
-            const int t = __ffs(tapmask) - 1;
-            tapmask &= tapmask - 1;
-            if (tapmask) issue(__ffs(tapmask) - 1);
-            gemm64<128>(sBuf[buf], kLd, w.dyn_conv_p + (size_t)t * 16384, acc, lane, wave);
-            if (tapmask) commit(sBuf[buf ^ 1]);
+            tapmask &= tapmask - 1;                            // the tap being multiplied now is already in bcur
+            const bool more = tapmask != 0;
+            const int tn = __ffs(tapmask) - 1;
+            // next stage's weights first (older in the in-order vmcnt queue), then the next activation tile
+            load_b(bnext, more ? w.dyn_conv_p + (size_t)tn * 16384 : w.dyn_dense_p, lane, wave);
+            if (more) issue(tn);
+            mma_tile<MT>(sBuf[buf], bcur, acc, lane);
+            if (more) commit(sBuf[buf ^ 1]);
             __syncthreads();
+            bcur = bnext;
             buf ^= 1;
         }
         // + bias + action planes, relu -> sX
+        load_b(bnext, w.pred_conv_p + (size_t)cell * 16384, lane, wave);
         const int n = wave * 32 + (lane & 31);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
@@ -241,13 +291,13 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
 
     // Dense 128 -> 128, relu = the new hidden state of this cell (games/tictactoe.py:184 / :191)
     zero_acc(acc);
-    gemm64<128>(sX, kLd, INITIAL ? w.rep_dense_p : w.dyn_dense_p, acc, lane, wave);
+    mma_tile<MT>(sX, bcur, acc, lane);
     {
         const float* bias = INITIAL ? w.rep_dense_b : w.dyn_dense_b;
         const int n = wave * 32 + (lane & 31);
         const float bn = bias[n];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
@@ -258,92 +308,113 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
     }
     __syncthreads();
 
-    if (!INITIAL) {
+    if (!INITIAL && tid < ROWS * 4) {
         // reward head partial: Flatten(1152) . w restricted to this cell (games/tictactoe.py:193-195)
         const int row = tid >> 2, q = tid & 3;
-        const float* wr = w.dyn_reward_w + cell * 128 + q * 32;
-        const float* h = sH + row * kLd + q * 32;
-        float s = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) s += h[j] * wr[j];
-        s += __shfl_xor(s, 1, 4);
-        s += __shfl_xor(s, 2, 4);
+        const float s = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
         if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = s;
     }
-
     // prediction Conv2D 3x3 valid over the 3x3 board = sum over cells of hidden'[cell] @ W[cell]: this cell's term
     zero_acc(acc);
-    gemm64<128>(sH, kLd, w.pred_conv_p + (size_t)cell * 16384, acc, lane, wave);
+    mma_tile<MT>(sH, bnext, acc, lane);
     {
         const int n = wave * 32 + (lane & 31);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
                 if (sRowOff[row] >= 0) ppart[((size_t)(row0 + row) * 9 + cell) * 128 + n] = acc[m][r];
             }
     }
+    if (trace && threadIdx.x == 0) {       // diagnostic timeline (mzdbg_net_set_trace): start, end [10 ns], placement
+        long long* tr = trace + 8 * (size_t)blockIdx.x;
+        tr[0] = t_start;
+        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
 }
 
-// Kernel B.  grid = ceil(B/64).  parent_block only tells which rows are skipped.
-template <bool INITIAL>
+// Kernel B.  grid = ceil(B / (32*MT)).  parent_block only tells which rows are skipped.
+template <bool INITIAL, int MT>
 __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, const int* __restrict__ parent_block,
                                                             const float* __restrict__ ppart, const float* __restrict__ rpart,
                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
                                                             float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
-    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
+    constexpr int ROWS = 32 * MT;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sW[10 * 128];       // value row + 9 policy rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRows;
+    const int row0 = blockIdx.x * ROWS;
     float* sX = sBuf[0];
     float* sH = sBuf[1];
+    BFrag bw;
+    load_b(bw, w.pred_dense_p, lane, wave);
+    for (int i = tid; i < 1280; i += kThreads) sW[i] = i < 128 ? w.pred_value_w[i] : w.pred_policy_w[i - 128];
     {   // relu(sum of the nine per-cell partial products + bias) (games/tictactoe.py:201)
-        const int n = tid & 127;
-        const float bn = w.pred_conv_b[n];
-        for (int r = tid >> 7; r < kRows; r += 2) {
+        const int c4 = tid & 31;
+        const float4 bn = *reinterpret_cast<const float4*>(w.pred_conv_b + 4 * c4);
+#pragma unroll 2
+        for (int r = tid >> 5; r < ROWS; r += 8) {
             const int b = row0 + r;
-            float s = 0.f;
+            float4 s = bn;
             if (b < B) {
-                const float* p = ppart + (size_t)b * 9 * 128 + n;
+                const float4* p = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
 #pragma unroll
-                for (int c = 0; c < 9; ++c) s += p[c * 128];
+                for (int c = 0; c < 9; ++c) {
+                    const float4 v = p[c * 32];
+                    s.x += v.x;
+                    s.y += v.y;
+                    s.z += v.z;
+                    s.w += v.w;
+                }
             }
-            sX[r * kLd + n] = fmaxf(s + bn, 0.f);
+            *reinterpret_cast<float4*>(sX + r * kLd + 4 * c4) =
+                make_float4(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f), fmaxf(s.z, 0.f), fmaxf(s.w, 0.f));
         }
     }
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[MT];
     zero_acc(acc);
-    gemm64<128>(sX, kLd, w.pred_dense_p, acc, lane, wave);              // Dense 128 -> 128 relu (:204)
-    store_acc_lds<true>(acc, w.pred_dense_b, sH, lane, wave);
+    mma_tile<MT>(sX, bw, acc, lane);                                    // Dense 128 -> 128 relu (:204)
+    store_acc_lds<MT, true>(acc, w.pred_dense_b, sH, lane, wave);
     __syncthreads();
-    const int row = tid >> 2, q = tid & 3, b = row0 + row;
-    const bool live = b < B && (INITIAL || !parent_block || parent_block[b] >= 0);
-    const float* h = sH + row * kLd + q * 32;
-    // value head (tanh, :206) and the 9 policy logits (:208)
-#pragma unroll 1
-    for (int o = 0; o < 10; ++o) {
-        const float* wo = (o == 0 ? w.pred_value_w : w.pred_policy_w + (o - 1) * 128) + q * 32;
-        float s = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) s += h[j] * wo[j];
-        s += __shfl_xor(s, 1, 4);
-        s += __shfl_xor(s, 2, 4);
-        if (q == 0 && live) {
-            if (o == 0) {
-                const float v = tanhf(s + w.pred_value_b);
-                out_value[b] = v;                   // to_scalar is the identity: support_size None (config.py:28)
-                if (out_value_raw) out_value_raw[b] = v;
-            } else {
-                out_logits[(size_t)b * 9 + (o - 1)] = s + w.pred_policy_b[o - 1];
+    if (tid < ROWS * 4) {
+        const int row = tid >> 2, q = tid & 3, b = row0 + row;
+        const bool live = b < B && (INITIAL || !parent_block || parent_block[b] >= 0);
+        const float* h = sH + row * kLd + q * 32;
+        // value head (tanh, :206) and the 9 policy logits (:208): 10 dots sharing the row's activations
+        float s[10];
+#pragma unroll
+        for (int o = 0; o < 10; ++o) s[o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(h + j);
+#pragma unroll
+            for (int o = 0; o < 10; ++o) {
+                const float4 wv = *reinterpret_cast<const float4*>(sW + o * 128 + q * 32 + j);
+                s[o] += a.x * wv.x + a.y * wv.y + a.z * wv.z + a.w * wv.w;
             }
         }
-    }
-    if (!INITIAL && q == 0 && live) {
-        float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) s += rpart[(size_t)b * 9 + c];
-        out_reward[b] = tanhf(s + w.dyn_reward_b);       // reward head, tanh (:194)
+        for (int o = 0; o < 10; ++o) {
+            s[o] += __shfl_xor(s[o], 1, 4);
+            s[o] += __shfl_xor(s[o], 2, 4);
+        }
+        if (q == 0 && live) {
+            const float v = tanhf(s[0] + w.pred_value_b);
+            out_value[b] = v;                       // to_scalar is the identity: support_size None (config.py:28)
+            if (out_value_raw) out_value_raw[b] = v;
+#pragma unroll
+            for (int o = 1; o < 10; ++o) out_logits[(size_t)b * 9 + (o - 1)] = s[o] + w.pred_policy_b[o - 1];
+            if (!INITIAL) {
+                float rs = 0.f;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) rs += rpart[(size_t)b * 9 + c];
+                out_reward[b] = tanhf(rs + w.dyn_reward_b);      // reward head, tanh (:194)
+            }
+        }
     }
 }
 
@@ -372,21 +443,26 @@ struct CartDev {
     float dyn_reward_b;
 };
 
-// One launch per call; grid = ceil(B/64).
-template <bool INITIAL>
+// One launch per call; grid = ceil(B / (32*MT)).  Six chained GEMM stages; each stage's weights are loaded into
+// registers while the previous stage multiplies.
+template <bool INITIAL, int MT>
 __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, const float* __restrict__ in_base,
                                                             const int* __restrict__ parent_block, long block_stride,
                                                             const int* __restrict__ action, float* __restrict__ out_hidden,
                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
                                                             float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
-    __shared__ __attribute__((aligned(16))) float sBuf[2][kRows * kLd];
-    __shared__ long sRowOff[kRows];
-    __shared__ float sAct[kRows];
+    constexpr int ROWS = 32 * MT;
+    constexpr int NSTG = MT * 4;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
+    __shared__ long sRowOff[ROWS];
+    __shared__ float sAct[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRows;
+    const int row0 = blockIdx.x * ROWS;
     float* sX = sBuf[0];
     float* sH = sBuf[1];
-    if (tid < kRows) {
+    BFrag b0, b1;
+    load_b(b0, INITIAL ? w.rep_dense_p : w.dyn_conv_p, lane, wave);
+    if (tid < ROWS) {
         const int b = row0 + tid;
         long off = -1;
         float a = 0.f;
@@ -403,14 +479,15 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
         sAct[tid] = a;
     }
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[MT];
+    const int n = wave * 32 + (lane & 31);
     if (INITIAL) {
         // scalar_to_support two-hot (utils.py:138-143, network.py:107-116) -> Conv1D k=4 valid 101 -> 128 relu
         // (games/cartpole.py:98): only <= 8 of the 404 inputs are non-zero, gathered on the VALU.
-        const int n = tid & 127;
+        const int nn = tid & 127;
         const float lo[4] = {-4.8f, -5.f, -0.418f, -5.f}, hi[4] = {4.8f, 5.f, 0.418f, 5.f};
-        const float bn = w.rep_conv_b[n];
-        for (int r = tid >> 7; r < kRows; r += 2) {
+        const float bn = w.rep_conv_b[nn];
+        for (int r = tid >> 7; r < ROWS; r += 2) {
             float s = bn;
             if (sRowOff[r] >= 0) {
 #pragma unroll
@@ -421,48 +498,48 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
                     const float p = y - fl;
                     const int il = (int)fl, ih = (int)ceilf(y);
                     // tf.one_hot yields an all-zero row for an out-of-range index
-                    if (ih >= 0 && ih <= 100) s += p * w.rep_conv[(pos * 101 + ih) * 128 + n];
-                    if (il >= 0 && il <= 100) s += (1.f - p) * w.rep_conv[(pos * 101 + il) * 128 + n];
+                    if (ih >= 0 && ih <= 100) s += p * w.rep_conv[(pos * 101 + ih) * 128 + nn];
+                    if (il >= 0 && il <= 100) s += (1.f - p) * w.rep_conv[(pos * 101 + il) * 128 + nn];
                 }
             }
-            sX[r * kLd + n] = fmaxf(s, 0.f);
+            sX[r * kLd + nn] = fmaxf(s, 0.f);
         }
+        load_b(b1, w.pred_dense1_p, lane, wave);
         __syncthreads();
         zero_acc(acc);
-        gemm64<128>(sX, kLd, w.rep_dense_p, acc, lane, wave);                 // Dense relu = hidden (:101)
+        mma_tile<MT>(sX, b0, acc, lane);                                      // Dense relu = hidden (:101)
     } else {
         // gather leaf.parent.hidden_state rows (agent.py:204) into LDS
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NSTG; ++i) {
             const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
             const long off = sRowOff[r];
             const float4 v = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(sH + r * kLd + c4 * 4) = v;
         }
+        load_b(b1, w.dyn_dense_p, lane, wave);
         __syncthreads();
         // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
         zero_acc(acc);
-        gemm64<128>(sH, kLd, w.dyn_conv_p, acc, lane, wave);
-        const int n = wave * 32 + (lane & 31);
+        mma_tile<MT>(sH, b0, acc, lane);
         const float bn = w.dyn_conv_b[n], pn = w.dyn_plane[n];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
                 sX[row * kLd + n] = fmaxf(acc[m][r] + bn + sAct[row] * pn, 0.f);
             }
+        load_b(b0, w.dyn_rdense_p, lane, wave);
         __syncthreads();
         zero_acc(acc);
-        gemm64<128>(sX, kLd, w.dyn_dense_p, acc, lane, wave);                 // Dense relu = hidden' (:108)
+        mma_tile<MT>(sX, b1, acc, lane);                                      // Dense relu = hidden' (:108)
+        load_b(b1, w.pred_dense1_p, lane, wave);
     }
-    {   // hidden state out (both modes)
-        const float* bias = INITIAL ? w.rep_dense_b : w.dyn_dense_b;
-        const int n = wave * 32 + (lane & 31);
-        const float bn = bias[n];
-        __syncthreads();                       // RECURRENT: every wave is done reading sH (the gathered input)
+    {   // hidden state out (both modes); sH's previous contents (the gathered input) are no longer read
+        const float bn = (INITIAL ? w.rep_dense_b : w.dyn_dense_b)[n];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
@@ -473,39 +550,38 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
     }
     __syncthreads();
     const int row = tid >> 2, q = tid & 3, b = row0 + row;
-    const bool live = sRowOff[row] >= 0;
+    const bool rowthread = tid < ROWS * 4;
+    const bool live = rowthread && sRowOff[rowthread ? row : 0] >= 0;
     if (!INITIAL) {
         // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114)
         zero_acc(acc);
-        gemm64<128>(sH, kLd, w.dyn_rdense_p, acc, lane, wave);
-        store_acc_lds<true>(acc, w.dyn_rdense_b, sX, lane, wave);
+        mma_tile<MT>(sH, b0, acc, lane);
+        store_acc_lds<MT, true>(acc, w.dyn_rdense_b, sX, lane, wave);
         __syncthreads();
-        const float* h = sX + row * kLd + q * 32;
-        const float* wr = w.dyn_reward_w + q * 32;
-        float s = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) s += h[j] * wr[j];
-        s += __shfl_xor(s, 1, 4);
-        s += __shfl_xor(s, 2, 4);
-        if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        if (rowthread) {
+            const float s = dot32x4(sX + row * kLd + q * 32, w.dyn_reward_w + q * 32);
+            if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        }
         __syncthreads();
     }
-    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124)
+    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124); b1 = pred_dense1 in both modes
+    load_b(b0, w.pred_dense2_p, lane, wave);
     zero_acc(acc);
-    gemm64<128>(sH, kLd, w.pred_dense1_p, acc, lane, wave);
-    store_acc_lds<true>(acc, w.pred_dense1_b, sX, lane, wave);
+    mma_tile<MT>(sH, b1, acc, lane);
+    store_acc_lds<MT, true>(acc, w.pred_dense1_b, sX, lane, wave);
+    load_b(b1, w.pred_value_p, lane, wave);
     __syncthreads();
     zero_acc(acc);
-    gemm64<128>(sX, kLd, w.pred_dense2_p, acc, lane, wave);
+    mma_tile<MT>(sX, b0, acc, lane);
     __syncthreads();
-    store_acc_lds<true>(acc, w.pred_dense2_b, sH, lane, wave);
+    store_acc_lds<MT, true>(acc, w.pred_dense2_b, sH, lane, wave);
     __syncthreads();
     // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
     zero_acc(acc);
-    gemm64<128>(sH, kLd, w.pred_value_p, acc, lane, wave);
-    store_acc_lds<false>(acc, w.pred_value_b, sX, lane, wave);
+    mma_tile<MT>(sH, b1, acc, lane);
+    store_acc_lds<MT, false>(acc, w.pred_value_b, sX, lane, wave);
     __syncthreads();
-    {
+    if (rowthread) {
         float* z = sX + row * kLd;
         float mx = -INFINITY;
         for (int j = q; j < 101; j += 4) mx = fmaxf(mx, z[j]);
@@ -533,15 +609,9 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
             out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
         }
         // policy logits: Dense 2 (:127)
-        const float* h = sH + row * kLd + q * 32;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const float* wo = w.pred_policy_w + o * 128 + q * 32;
-            float s = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < 32; ++j) s += h[j] * wo[j];
-            s += __shfl_xor(s, 1, 4);
-            s += __shfl_xor(s, 2, 4);
+            const float s = dot32x4(sH + row * kLd + q * 32, w.pred_policy_w + o * 128 + q * 32);
             if (q == 0 && live) out_logits[(size_t)b * 2 + o] = s + w.pred_policy_b[o];
         }
     }
@@ -583,6 +653,7 @@ struct mz_net {
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
+    long long* trace = nullptr;       // diagnostic: per-workgroup timeline of the cell kernel (device, 3 x grid)
 };
 
 namespace {
@@ -594,7 +665,7 @@ int ensure_scratch(mz_net* net, int batch) {
     if (net->rpart) (void)hipFree(net->rpart);
     net->ppart = net->rpart = nullptr;
     net->scratch_cap = 0;
-    const int cap = (batch + kRows - 1) / kRows * kRows;
+    const int cap = (batch + 63) / 64 * 64;
     MZ_HIP(hipMalloc(reinterpret_cast<void**>(&net->ppart), (size_t)cap * 9 * 128 * sizeof(float)));
     MZ_HIP(hipMalloc(reinterpret_cast<void**>(&net->rpart), (size_t)cap * 9 * sizeof(float)));
     net->scratch_cap = cap;
@@ -830,10 +901,36 @@ int mz_net_set_stream(mz_net_t* net, void* stream) {
 
 int64_t mz_net_training_steps(mz_net_t* net) { return net ? net->training_steps : -1; }
 
+/* Diagnostic, not part of include/mzhip.h: device buffer of 3 int64 per workgroup of the next cell-kernel launches. */
+int mzdbg_net_set_trace(mz_net_t* net, long long* device_buf) {
+    if (net) net->trace = device_buf;
+    return MZ_OK;
+}
+
 int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     net->mid_event = static_cast<hipEvent_t>(hip_event);
     return MZ_OK;
+}
+
+// Rows per workgroup tile (32 or 64).  64 halves the weight traffic per game; 32 doubles the number of
+// workgroups, which wins while a 64-row grid cannot fill the 256 CUs.  MZ_TILE_ROWS overrides (experiments).
+static int cell_order() {
+    static const int v = [] {
+        const char* e = getenv("MZ_CELL_ORDER");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
+static int tile_rows(const mz_net* net, int batch) {
+    static const int forced = [] {
+        const char* e = getenv("MZ_TILE_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 32 || forced == 64) return forced;
+    const int wg64 = (batch + 63) / 64 * (net->kind == MZ_NET_TICTACTOE ? 9 : 1);
+    return wg64 >= 512 ? 64 : 32;
 }
 
 int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
@@ -843,18 +940,29 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
     if (batch == 0) return MZ_OK;
     MZ_REQUIRE(observation && out_hidden && out_value && out_logits, "observation/out_hidden/out_value/out_logits is NULL");
     MZ_HIP(hipSetDevice(net->device));
-    const int nrb = (batch + kRows - 1) / kRows;
+    const int rows = tile_rows(net, batch);
+    const int nrb = (batch + rows - 1) / rows;
+    hipStream_t st = net->stream;
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
-        ttt_cell_kernel<true><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
-                                                                    out_hidden, net->ppart, net->rpart);
-        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
-        ttt_head_kernel<true><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                                out_value, out_logits, out_value_raw);
+        if (rows == 64)
+            ttt_cell_kernel<true, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
+                                                                  out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+        else
+            ttt_cell_kernel<true, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
+                                                                  out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+        const int nhb = (batch + 31) / 32;
+        ttt_head_kernel<true, 1><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                          out_value, out_logits, out_value_raw);
     } else {
-        cartpole_kernel<true><<<nrb, kThreads, 0, net->stream>>>(net->cart, batch, observation, nullptr, 0, nullptr,
-                                                               out_hidden, nullptr, out_value, out_logits, out_value_raw);
+        if (rows == 64)
+            cartpole_kernel<true, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
+                                                              out_hidden, nullptr, out_value, out_logits, out_value_raw);
+        else
+            cartpole_kernel<true, 1><<<nrb, kThreads, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
+                                                              out_hidden, nullptr, out_value, out_logits, out_value_raw);
     }
     return launch_status("initial inference");
 }
@@ -869,20 +977,30 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                "hidden_base/action/out_hidden/out_reward/out_value/out_logits is NULL");
     MZ_REQUIRE(block_stride >= 0, "block_stride must be >= 0");
     MZ_HIP(hipSetDevice(net->device));
-    const int nrb = (batch + kRows - 1) / kRows;
+    const int rows = tile_rows(net, batch);
+    const int nrb = (batch + rows - 1) / rows;
+    hipStream_t st = net->stream;
+    const long bs = (long)block_stride;
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
-        ttt_cell_kernel<false><<<9 * nrb, kThreads, 0, net->stream>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                     (long)block_stride, action, out_hidden, net->ppart,
-                                                                     net->rpart);
-        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
-        ttt_head_kernel<false><<<nrb, kThreads, 0, net->stream>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                                 out_reward, out_value, out_logits, out_value_raw);
+        if (rows == 64)
+            ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+        else
+            ttt_cell_kernel<false, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+        const int nhb = (batch + 31) / 32;
+        ttt_head_kernel<false, 1><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                           out_reward, out_value, out_logits, out_value_raw);
     } else {
-        cartpole_kernel<false><<<nrb, kThreads, 0, net->stream>>>(net->cart, batch, hidden_base, parent_block,
-                                                                (long)block_stride, action, out_hidden, out_reward,
-                                                                out_value, out_logits, out_value_raw);
+        if (rows == 64)
+            cartpole_kernel<false, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs, action,
+                                                               out_hidden, out_reward, out_value, out_logits, out_value_raw);
+        else
+            cartpole_kernel<false, 1><<<nrb, kThreads, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs, action,
+                                                               out_hidden, out_reward, out_value, out_logits, out_value_raw);
     }
     return launch_status("recurrent inference");
 }
