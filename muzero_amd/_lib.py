@@ -6,7 +6,7 @@ import os
 from .exceptions import MuZeroError, MuZeroHipError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmzhip.so')
+LIB_PATH = os.environ.get('MZ_LIB') or os.path.join(_HERE, 'libmzhip.so')     # MZ_LIB: experiment builds only
 
 c_void_p, c_int32, c_int64, c_double = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -137,6 +138,8 @@ struct TttDev {
     const float* pred_value_w;  // [128]
     const float* pred_policy_w; // [9][128]
     const float* pred_policy_b; // [9]
+    const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
+    int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     float dyn_reward_b, pred_value_b;
 };
 
@@ -333,6 +336,378 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
         tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
         tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
                 (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+}
+
+// acc += sA[32][128] * W held in b.  As soon as the four MFMAs of k-step kb have consumed b.v[kb], that register is
+// re-loaded with the NEXT stage's weights (in-place ring: every load gets a whole stage, ~4096 MFMA cycles, to land,
+// and there is one weight set in registers instead of two), and the next activation tile is requested on the first
+// k-steps.  Issuing a stage's 80 KB up front instead stalls every wave of the workgroup on the vector-memory path.
+template <int KB>
+__device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BFrag& b, f32x16& acc, f32x16& acc2,
+                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
+                                            float4 (&stg)[4]) {
+    // LDS fragment ring, two k-steps ahead: the read issued here is consumed 8 MFMAs (512 cycles) later
+    if (KB + 2 < 16) af[(KB + 2) % 3] = *reinterpret_cast<const float4*>(ap + (KB + 2) * 8);
+    const float4 a = af[KB % 3];
+    const float4 bv = b.v[KB];
+    // two independent accumulation chains: a dependent 32x32x2 chain alone issues every ~88 cycles, not 64
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc2, 0, 0, 0);
+#ifndef MZ_EXP_NOVMEM
+    b.v[KB] = wnext[KB * 256];
+    if (KB < 4) stg[KB] = *reinterpret_cast<const float4*>(sptr[KB] + src);
+#endif
+    // pin the interleave (hipcc otherwise sinks all 20 loads behind the last MFMA, right in front of the epilogue
+    // that waits for them): one LDS fragment read, 4 MFMA, then this k-step's VMEM reads
+#ifndef MZ_EXP_NOSCHED
+    if (KB + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#ifndef MZ_EXP_NOVMEM
+    if (KB < 4)
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    else
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
+#endif
+}
+
+template <int... KB>
+__device__ __forceinline__ void mma_steps_pf(std::integer_sequence<int, KB...>, const float* ap, float4 (&af)[3], BFrag& b,
+                                             f32x16& acc, f32x16& acc2, const float4* __restrict__ wnext,
+                                             const float* const (&sptr)[4], int src, float4 (&stg)[4]) {
+    (mma_step_pf<KB>(ap, af, b, acc, acc2, wnext, sptr, src, stg), ...);
+}
+
+__device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& acc, f32x16& acc2, int lane,
+                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
+                                            float4 (&stg)[4]) {
+    const float* ap = sA + (lane & 31) * kLd + 4 * (lane >> 5);
+    float4 af[3];
+    af[0] = *reinterpret_cast<const float4*>(ap);
+    af[1] = *reinterpret_cast<const float4*>(ap + 8);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two ring-priming reads come first
+    mma_steps_pf(std::make_integer_sequence<int, 16>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
+}
+
+// Recurrent inference, kernel A', uniform-cost jobs.  A job = 32 games x a group of board cells chosen so that every
+// workgroup runs 16-18 GEMM stages: {centre, corner 0} = 11+6, {edges 1,3} = 8+8, {edges 5,7} = 8+8,
+// {corners 2,6,8} = 6+6+6 (a cell costs its valid conv taps + Dense + prediction-conv term).  4096 games -> 512 jobs
+// = two per CU on 256 CUs, all finishing together (the per-cell grid left a 45-us tail of corner cells).
+// Stage s multiplies with the weights and the tile requested during stage s-1.
+// grid = 8 * 4 * ceil(ceil(B/32) / 8): block b -> XCD label x = b%8, i = b/8, job = i%4, row block = (i/4)*8 + x, so
+// the four jobs of a row block share an L2 (speed only).
+__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, const float* __restrict__ in_base,
+                                                              const int* __restrict__ parent_block, long block_stride,
+                                                              const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                              float* __restrict__ ppart, float* __restrict__ rpart,
+                                                              long long* __restrict__ trace) {
+    constexpr int ROWS = 32;
+    __shared__ __attribute__((aligned(16))) float sTile[2][ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sX[ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sH[ROWS * kLd];
+    __shared__ long sRowOff[ROWS];
+    __shared__ int sAct[ROWS];
+    __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
+    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
+    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
+    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
+    const int n = wave * 32 + (lane & 31);
+    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_p) + n * 2 + (lane >> 5);   // + weights offset / 4
+
+    BFrag bw;
+    const int4 D0 = w.job_desc[dbase];
+    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
+    load_b(bw, w.dyn_conv_p + (size_t)D0.z * 16384, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            const int pb = parent_block ? parent_block[b] : 0;
+            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
+            a = action[b];
+            if (a < 0 || a > 8) a = 0;
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    const float* sptr[4];
+    unsigned svalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+        const long off = sRowOff[r];
+        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
+        if (off >= 0) svalid |= 1u << i;
+    }
+    float4 stg[4];
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            const bool ok = (svalid >> i) & 1u;
+            *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
+                make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
+        }
+    };
+    // LDS tile -> global rows (stride `ld` floats), 16-B coalesced, skipped rows masked
+    auto copy_out = [&](const float* sSrc, float* dst, int ld) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            if ((svalid >> i) & 1u)
+                *reinterpret_cast<float4*>(dst + (size_t)(row0 + r) * ld + c4 * 4) =
+                    *reinterpret_cast<const float4*>(sSrc + r * kLd + c4 * 4);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
+    commit(sTile[0]);
+    __syncthreads();
+
+    f32x16 acc, acc2;
+    int buf = 0;
+#pragma unroll 1
+    for (int d = d0; d < d1; ++d) {
+        const int4 Dc = sDesc[d];
+        const bool has_next = d + 1 < d1;
+        const int4 Dn = sDesc[has_next ? d + 1 : d];
+        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
+        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
+        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
+        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
+        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
+        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
+        const float* wn = nkind == 0 ? w.dyn_conv_p + (size_t)ntap * 16384
+                        : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
+        const bool gather = has_next && nkind == 0;
+        const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
+        if (kind != 0 || first_tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = 0.f;
+                acc2[r] = 0.f;
+            }
+        }
+        float ab[16];
+        if (kind == 0 && last_tap) {
+            // last tap of a cell: request conv bias + action-plane bias of each accumulator row now, so the loads
+            // land under the MFMAs (action planes of the one-hot encoder are constant per cell: network.py:14-40)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
+        }
+        mma_tile_pf(sA, bw, acc, acc2, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 0) {
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + ab[r], 0.f);
+            }
+            if (gather) commit(sTile[buf ^ 1]);
+            __syncthreads();
+            if (gather) buf ^= 1;
+        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            const float bn = w.dyn_dense_b[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + bn, 0.f);
+            __syncthreads();
+            copy_out(sH, out_hidden + cell * 128, 1152);
+            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
+                const int row = tid >> 2, q = tid & 3;
+                const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
+                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
+            }
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = acc[r] + acc2[r];
+            if (gather) commit(sTile[buf ^ 1]);
+            __syncthreads();
+            if (gather) buf ^= 1;
+            copy_out(sX, ppart + cell * 128, 1152);
+        }
+    }
+    if (trace && threadIdx.x == 0) {
+        long long* tr = trace + 8 * (size_t)blockIdx.x;
+        tr[0] = t_start;
+        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[3] = job;
+    }
+}
+
+// Diagnostic twin of ttt_job_kernel with in-kernel segment stamps (tools/trace_cell.py); never used by the product path.
+__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, int B, const float* __restrict__ in_base,
+                                                              const int* __restrict__ parent_block, long block_stride,
+                                                              const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                              float* __restrict__ ppart, float* __restrict__ rpart,
+                                                              long long* __restrict__ trace) {
+    constexpr int ROWS = 32;
+    __shared__ __attribute__((aligned(16))) float sTile[2][ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sX[ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sH[ROWS * kLd];
+    __shared__ long sRowOff[ROWS];
+    __shared__ int sAct[ROWS];
+    __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
+    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
+    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
+    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
+    const int n = wave * 32 + (lane & 31);
+    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_p) + n * 2 + (lane >> 5);   // + weights offset / 4
+
+    BFrag bw;
+    const int4 D0 = w.job_desc[dbase];
+    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
+    load_b(bw, w.dyn_conv_p + (size_t)D0.z * 16384, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            const int pb = parent_block ? parent_block[b] : 0;
+            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
+            a = action[b];
+            if (a < 0 || a > 8) a = 0;
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    const float* sptr[4];
+    unsigned svalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+        const long off = sRowOff[r];
+        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
+        if (off >= 0) svalid |= 1u << i;
+    }
+    float4 stg[4];
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            const bool ok = (svalid >> i) & 1u;
+            *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
+                make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
+        }
+    };
+    // LDS tile -> global rows (stride `ld` floats), 16-B coalesced, skipped rows masked
+    auto copy_out = [&](const float* sSrc, float* dst, int ld) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            if ((svalid >> i) & 1u)
+                *reinterpret_cast<float4*>(dst + (size_t)(row0 + r) * ld + c4 * 4) =
+                    *reinterpret_cast<const float4*>(sSrc + r * kLd + c4 * 4);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
+    commit(sTile[0]);
+    __syncthreads();
+
+    f32x16 acc, acc2;
+    int buf = 0;
+    int seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0;      // diagnostic: setup / mma / epilogue+barrier / after-barrier [10 ns]
+    long long t_last = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const int t_pro = (int)(t_last - t_start);
+#define MZ_SEG(x)                                                            \
+    if (trace) {                                                             \
+        const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); \
+        x += (int)(now_ - t_last);                                           \
+        t_last = now_;                                                       \
+    }
+#pragma unroll 1
+    for (int d = d0; d < d1; ++d) {
+        const int4 Dc = sDesc[d];
+        const bool has_next = d + 1 < d1;
+        const int4 Dn = sDesc[has_next ? d + 1 : d];
+        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
+        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
+        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
+        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
+        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
+        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
+        const float* wn = nkind == 0 ? w.dyn_conv_p + (size_t)ntap * 16384
+                        : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
+        const bool gather = has_next && nkind == 0;
+        const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
+        if (kind != 0 || first_tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = 0.f;
+                acc2[r] = 0.f;
+            }
+        }
+        float ab[16];
+        if (kind == 0 && last_tap) {
+            // last tap of a cell: request conv bias + action-plane bias of each accumulator row now, so the loads
+            // land under the MFMAs (action planes of the one-hot encoder are constant per cell: network.py:14-40)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
+        }
+        MZ_SEG(seg0)
+        mma_tile_pf(sA, bw, acc, acc2, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        MZ_SEG(seg1)
+        if (kind == 0) {
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + ab[r], 0.f);
+            }
+            if (gather) commit(sTile[buf ^ 1]);
+            __syncthreads();
+            MZ_SEG(seg2)
+            if (gather) buf ^= 1;
+        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            const float bn = w.dyn_dense_b[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + bn, 0.f);
+            __syncthreads();
+            MZ_SEG(seg2)
+            copy_out(sH, out_hidden + cell * 128, 1152);
+            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
+                const int row = tid >> 2, q = tid & 3;
+                const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
+                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
+            }
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = acc[r] + acc2[r];
+            if (gather) commit(sTile[buf ^ 1]);
+            __syncthreads();
+            MZ_SEG(seg2)
+            if (gather) buf ^= 1;
+            copy_out(sX, ppart + cell * 128, 1152);
+        }
+        MZ_SEG(seg3)
+    }
+#undef MZ_SEG
+    if (trace && threadIdx.x == 0) {
+        long long* tr = trace + 8 * (size_t)blockIdx.x;
+        tr[0] = t_start;
+        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[3] = job;
+        tr[4] = ((long long)t_pro << 32) | (unsigned)seg0;
+        tr[5] = ((long long)seg1 << 32) | (unsigned)seg2;
+        tr[6] = seg3;
     }
 }
 
@@ -774,6 +1149,37 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         off.push_back(pk.add(pred_policy_b, 9));                       // 15
         net->ttt.dyn_reward_b = dyn_reward_b[0];
         net->ttt.pred_value_b = pred_value_b[0];
+        // stage descriptors of the four uniform-cost jobs: (kind | 8*first tap | 16*last tap, cell, tap, source cell)
+        static const int kJobCells[4][3] = {{4, 0, -1}, {1, 3, -1}, {5, 7, -1}, {2, 6, 8}};
+        std::vector<float> desc;      // int4 bit patterns stored in the float buffer
+        auto push = [&](int a, int b, int c, int d) {
+            const int v[4] = {a, b, c, d};
+            for (int i = 0; i < 4; ++i) {
+                float f;
+                memcpy(&f, &v[i], 4);
+                desc.push_back(f);
+            }
+        };
+        for (int j = 0; j < 4; ++j) {
+            net->ttt.job_first[j] = (int)desc.size() / 4;
+            for (int ci = 0; ci < 3; ++ci) {
+                const int c = kJobCells[j][ci];
+                if (c < 0) continue;
+                int valid[9], nv = 0;
+                for (int t = 0; t < 9; ++t) {
+                    const int ni = c / 3 + t / 3 - 1, nj = c % 3 + t % 3 - 1;
+                    if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) valid[nv++] = t;
+                }
+                for (int i = 0; i < nv; ++i) {
+                    const int t = valid[i];
+                    push(0 | (i == 0 ? 8 : 0) | (i == nv - 1 ? 16 : 0), c, t, (c / 3 + t / 3 - 1) * 3 + (c % 3 + t % 3 - 1));
+                }
+                push(1, c, 0, 0);
+                push(2, c, 0, 0);
+            }
+        }
+        net->ttt.job_first[4] = (int)desc.size() / 4;
+        off.push_back(pk.add(desc));                                   // 16
     } else {
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
@@ -855,6 +1261,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         t.pred_value_w = d + off[13];
         t.pred_policy_w = d + off[14];
         t.pred_policy_b = d + off[15];
+        t.job_desc = reinterpret_cast<const int4*>(d + off[16]);
     } else {
         CartDev& c = net->cart;
         c.rep_conv = d + off[0];
@@ -984,12 +1391,24 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
-        if (rows == 64)
+        static const bool per_cell = getenv("MZ_CELL_KERNEL") != nullptr;      // the older per-cell grid (experiments)
+        if (!per_cell) {
+            const int nrb32 = (batch + 31) / 32;
+            if (net->trace)
+                ttt_job_kernel_traced<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(
+                    net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart, net->trace);
+            else
+                ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
+                                                                            action, out_hidden, net->ppart, net->rpart,
+                                                                            nullptr);
+        } else if (rows == 64)
             ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+                                                                   out_hidden, net->ppart, net->rpart, cell_order(),
+                                                                   net->trace);
         else
             ttt_cell_kernel<false, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
+                                                                   out_hidden, net->ppart, net->rpart, cell_order(),
+                                                                   net->trace);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 31) / 32;
         ttt_head_kernel<false, 1><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,

@@ -10,7 +10,7 @@ hid = torch.rand(2, T, 1152, device='cuda')
 pb = torch.zeros(T, dtype=torch.int32, device='cuda'); act = torch.randint(0, 9, (T,), device='cuda', dtype=torch.int32)
 r = torch.empty(T, device='cuda'); v = torch.empty(T, device='cuda'); lg = torch.empty(T, 9, device='cuda')
 rows = int(os.environ.get('MZ_TILE_ROWS', '64'))
-nwg = 9 * (T // rows)
+nwg = 9 * (T // rows) if os.environ.get('MZ_CELL_KERNEL') else 32 * ((T // 32 + 7) // 8)
 trace = torch.zeros(nwg * 8, dtype=torch.int64, device='cuda')
 for _ in range(3):
     net.recurrent_inference_pool(hid, pb, act, 1, r, v, lg)
@@ -24,8 +24,12 @@ start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0        # microsecond
 hw = t[:, 2] & 0xffffffff; xcc = (t[:, 2] >> 32) & 0xf; mma = seg[:, 2]
 cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
 print('kernel span us', end.max(), 'n wg', nwg)
+if not os.environ.get('MZ_CELL_KERNEL'):
+    sg = np.stack([t[:, 4] >> 32, t[:, 4] & 0xffffffff, t[:, 5] >> 32, t[:, 5] & 0xffffffff, t[:, 6]], 1) / 100.0
+    for j in range(4):
+        print('job', j, '[prologue, setup, mma, epilogue+barrier, after-barrier] us', np.round(sg[t[:, 3] == j].mean(0), 1).tolist(), 'total', round(float((end - start)[t[:, 3] == j].mean()), 1))
 order = int(os.environ.get('MZ_CELL_ORDER', '0'))
-cells = np.array([4, 1, 3, 5, 7, 0, 2, 6, 8])[np.arange(nwg) // (T // rows)] if order == 0 else np.arange(nwg) % 9
+cells = (np.array([4, 1, 3, 5, 7, 0, 2, 6, 8])[np.arange(nwg) // (T // rows)] if order == 0 else np.arange(nwg) % 9) if os.environ.get('MZ_CELL_KERNEL') else np.array([4, 1, 5, 2])[t[:, 3]]
 for name, sel in (('center', cells == 4), ('edge', np.isin(cells, [1, 3, 5, 7])), ('corner', np.isin(cells, [0, 2, 6, 8]))):
     d = (end - start)[sel]
     print(name, 'segments[prolog,ld,mma,commit,barrier,copy,epi1,dense,epi2,pred]', np.round(seg[sel].mean(0), 1).tolist())
