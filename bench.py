@@ -136,46 +136,34 @@ class HipEvents:
         return ms.value
 
 
-class _InferenceEvents:
-    """Per recurrent_inference call of the timed region: event before, event between the two launches (recorded by
-    the library, mz_net_set_mid_event), event after, event after the tree step."""
+class MoveEvents:
+    """4 HIP events per simulation, recorded by mz_search_move on the launch stream: before the inference, between its
+    two launches (TicTacToe: job kernel | head kernel), after it, after the tree step.  One set per timed step."""
 
-    def __init__(self, net, two_launches):
-        self.ev = HipEvents()
-        self.net, self.two = net, two_launches
-        self.calls, self.on = [], False
+    def __init__(self, num_simulations, two_launches):
+        import ctypes
+        self.ev, self.N, self.two, self.ct = HipEvents(), num_simulations, two_launches, ctypes
+        self.sets = []
 
-    def before_inference(self, s):
-        if self.on:
-            self._cur = [self.ev.record(), None, None, None]
-            if self.two:
-                self._cur[1] = self.ev.new()
-                self.net._lib.mz_net_set_mid_event(self.net._h, self._cur[1])
-
-    def after_inference(self, s):
-        if self.on:
-            self._cur[2] = self.ev.record()
-
-    def after_tree(self, s):
-        if self.on:
-            self._cur[3] = self.ev.record()
-            self.calls.append(self._cur)
-
-    def stop(self):
-        self.on = False
-        if self.two:
-            self.net._lib.mz_net_set_mid_event(self.net._h, None)
+    def new_set(self):
+        arr = (self.ct.c_void_p * (4 * self.N))()
+        for i in range(4 * self.N):
+            arr[i] = self.ev.new()
+        self.sets.append(arr)
+        return arr
 
     def durations(self):
         """-> (first kernel s, second kernel s, tree step s), each averaged over the timed region"""
         first, second, tree = [], [], []
-        for e0, em, e1, e2 in self.calls:
-            if em is not None:
-                first.append(self.ev.elapsed_ms(e0, em))
-                second.append(self.ev.elapsed_ms(em, e1))
-            else:
-                first.append(self.ev.elapsed_ms(e0, e1))
-            tree.append(self.ev.elapsed_ms(e1, e2))
+        for arr in self.sets:
+            for s in range(self.N):
+                e0, em, e1, e2 = (self.ct.c_void_p(arr[4 * s + j]) for j in range(4))
+                if self.two:
+                    first.append(self.ev.elapsed_ms(e0, em))
+                    second.append(self.ev.elapsed_ms(em, e1))
+                else:
+                    first.append(self.ev.elapsed_ms(e0, e1))
+                tree.append(self.ev.elapsed_ms(e1, e2))
         mean = lambda v: float(np.mean(v)) * 1e-3 if v else None
         return mean(first), mean(second), mean(tree)
 
@@ -201,7 +189,7 @@ class NetworkMove:
             cells = torch.randint(0, 3, (T, 9), generator=g, device=device)
             to_play = torch.randint(0, 2, (T, 1), generator=g, device=device).expand(T, 9)
             self.obs = torch.stack([(cells == 0), (cells == 1), to_play.bool()], -1).float().reshape(T, 27).contiguous()
-            self.dominant = 'ttt_cell_kernel<recurrent>'
+            self.dominant = 'ttt_job_kernel'
             # SURVEY.md 8(d) terms this kernel covers per evaluation: conv 49*137*128, dense 9*128*128,
             # reward 1152, prediction conv 9*128*128 (multiply-adds x2)
             self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
@@ -213,13 +201,13 @@ class NetworkMove:
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
-        self.hooks = _InferenceEvents(self.net, two_launches=(wl['net'] == 'tictactoe'))
+        self.hooks = MoveEvents(wl['N'], two_launches=(wl['net'] == 'tictactoe'))
         self.gather = TrajectoryGather(T, A, device) if world > 1 else None
 
     def run(self, timed_events=False):
-        self.hooks.on = timed_events
-        visits, root_value, minmax, policy, action = self.search.run(self.obs, self.noise, self.u, self.temperature,
-                                                                     hooks=self.hooks)
+        events = self.hooks.new_set() if timed_events else None
+        visits, root_value, minmax, policy, action = self.search.run_native(self.obs, self.noise, self.u,
+                                                                            self.temperature, events=events)
         if self.gather is not None:      # the one exchange step: search statistics of this move to every rank
             self.gather.start(policy, root_value, action)
         return visits, action
@@ -284,6 +272,8 @@ def main():
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--event-every', type=int, default=4,
+                    help='record the per-kernel HIP events on every K-th timed step (each record costs stream time)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -315,8 +305,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        move.run(timed_events=True)
+    for i in range(args.steps):
+        move.run(timed_events=(i % args.event_every == 0))
     if with_net:
         move.finish()
     torch.cuda.synchronize()
@@ -338,7 +328,6 @@ def main():
     tree_bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
     if with_net:
-        move.hooks.stop()
         k1, k2, tree_s = move.hooks.durations()
         flops_launch = wl['T'] * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12

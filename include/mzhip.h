@@ -192,6 +192,41 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                        int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
                        float* out_value, float* out_logits, float* out_value_raw);
 
+/* ---- one move of T games, enqueued natively (batched MCTSAgent.make_move, reference agent.py:219-232) ------- */
+
+typedef struct mz_move_io {
+    int32_t num_trees;             /* T: must equal the pool's */
+    int32_t num_simulations;       /* N <= the pool's max_simulations */
+    int32_t hidden_size;           /* H of the network */
+    int32_t reserved;
+    void* stream;                  /* the hipStream_t the pool and the net launch on (for the timing events) */
+    const float* observation;      /* [T, obs] f32 */
+    const int32_t* legal;          /* [T, A] i32 or NULL (all legal) */
+    const int32_t* n_legal;        /* [T] i32 or NULL */
+    const double* noise;           /* [T, A] f64 Dirichlet draws (agent.py:172) */
+    double noise_frac;             /* MCTSConfig.root_exploration_fraction */
+    const double* u;               /* [T] f64 uniforms for the action sampling */
+    const double* temperature;     /* [T] f64 */
+    float* hidden;                 /* workspace [N+1][T][H] f32: block s+1 = hidden states of simulation s */
+    float* logits;                 /* workspace [T, A] f32 */
+    float* reward;                 /* workspace [T] f32 */
+    float* value;                  /* workspace [T] f32 */
+    int32_t* parent_block;         /* workspace [T] i32 */
+    int32_t* action;               /* workspace [T] i32 */
+    int32_t* out_visits;           /* [T, A] i32 or NULL */
+    double* out_root_value;        /* [T] f64 or NULL */
+    double* out_minmax;            /* [T, 2] f64 or NULL */
+    float* out_policy;             /* [T, A] f32 or NULL */
+    int32_t* out_action;           /* [T] i32 or NULL */
+    void** events;                 /* NULL, or HOST array of 4*N hipEvent_t recorded per simulation: before the
+                                      inference, between its two launches (if it has two), after it, after the
+                                      tree step (measurement only) */
+} mz_move_io_t;
+
+/* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in
+ * the loop, root statistics and action sampling -- about 3N+6 launches on the stream, no host synchronisation. */
+int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,17 @@ class PoolConfig(ctypes.Structure):
                 ('known_max', c_double), ('log_table', c_void_p)]
 
 
+class MoveIO(ctypes.Structure):
+    """mz_move_io_t"""
+    _fields_ = [('num_trees', c_int32), ('num_simulations', c_int32), ('hidden_size', c_int32), ('reserved', c_int32),
+                ('stream', c_void_p), ('observation', c_void_p), ('legal', c_void_p), ('n_legal', c_void_p),
+                ('noise', c_void_p), ('noise_frac', c_double), ('u', c_void_p), ('temperature', c_void_p),
+                ('hidden', c_void_p), ('logits', c_void_p), ('reward', c_void_p), ('value', c_void_p),
+                ('parent_block', c_void_p), ('action', c_void_p), ('out_visits', c_void_p),
+                ('out_root_value', c_void_p), ('out_minmax', c_void_p), ('out_policy', c_void_p),
+                ('out_action', c_void_p), ('events', c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/mzhip.h declares
 PROTOTYPES = {
     'mz_last_error': (ctypes.c_char_p, []),
@@ -51,6 +62,7 @@ PROTOTYPES = {
     'mz_net_training_steps': (c_int64, [c_void_p]),
     'mz_net_set_mid_event': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_search_move': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(MoveIO)]),
     'mz_infer_recurrent': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
 }

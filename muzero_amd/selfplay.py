@@ -14,12 +14,23 @@ Games shard over GPUs as independent ranks (one process per GPU); the only excha
 an all-gather of each move's search statistics (root visit distribution, root value, chosen action) -- what the
 reference's agents send to the replay buffer (agent.py:231, agent_services.py:54).
 """
+import ctypes
 from typing import Optional
 
 import torch
 
+from . import _lib
 from .exceptions import MuZeroError
-from .tree_pool import TreePool
+from .network import Network
+from .tree_pool import TreePool, _check_tensor
+
+
+def shard_bounds(total_games: int, rank: int, world: int):
+    """Contiguous block partition of the games over the ranks: games are independent (fresh root and MinMaxStats
+    per move, agent.py:220-221), so a shard needs nothing from the others during a search."""
+    base, extra = divmod(total_games, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
 
 
 class LockstepSearch:
@@ -42,11 +53,47 @@ class LockstepSearch:
         self.reward = torch.empty(self.T, **f32)
         self.value = torch.empty(self.T, **f32)
         self.frac = m.root_exploration_fraction
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.out_visits = torch.empty(self.T, self.A, **i32)
+        self.out_root_value = torch.empty(self.T, dtype=torch.float64, device=self.device)
+        self.out_minmax = torch.empty(self.T, 2, dtype=torch.float64, device=self.device)
+        self.out_policy = torch.empty(self.T, self.A, **f32)
+        self.out_action = torch.empty(self.T, **i32)
+        self.native = isinstance(network, Network)
+
+    def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None):
+        """The whole move enqueued by one C call (mz_search_move): same launches as run(), no interpreter time
+        between them.  `events`: optional ctypes array of 4*N hipEvent_t (measurement).  Results are written to the
+        search's own out_* tensors, which are returned."""
+        if not self.native:
+            raise MuZeroError('run_native needs a HIP-backed muzero_amd.network.Network')
+        pool, net, dev = self.pool, self.network, self.device
+        pool._sync_stream()
+        net._sync_stream()
+        obs = _check_tensor('observation', observation, torch.float32, (self.T, net.observation_size), dev)
+        io = _lib.MoveIO(
+            num_trees=self.T, num_simulations=self.N, hidden_size=net.hidden_size, stream=pool._stream,
+            observation=obs,
+            legal=None if legal is None else _check_tensor('legal', legal, torch.int32, (self.T, self.A), dev),
+            n_legal=None if n_legal is None else _check_tensor('n_legal', n_legal, torch.int32, (self.T,), dev),
+            noise=_check_tensor('noise', noise, torch.float64, (self.T, self.A), dev), noise_frac=self.frac,
+            u=_check_tensor('u', u, torch.float64, (self.T,), dev),
+            temperature=_check_tensor('temperature', temperature, torch.float64, (self.T,), dev),
+            hidden=self.hidden.data_ptr(), logits=self.logits.data_ptr(), reward=self.reward.data_ptr(),
+            value=self.value.data_ptr(), parent_block=pool._parent.data_ptr(), action=pool._action.data_ptr(),
+            out_visits=self.out_visits.data_ptr(), out_root_value=self.out_root_value.data_ptr(),
+            out_minmax=self.out_minmax.data_ptr(), out_policy=self.out_policy.data_ptr(),
+            out_action=self.out_action.data_ptr(),
+            events=None if events is None else ctypes.cast(events, ctypes.c_void_p))
+        _lib.check(_lib.load().mz_search_move(pool._h, net._h, ctypes.byref(io)))
+        return self.out_visits, self.out_root_value, self.out_minmax, self.out_policy, self.out_action
 
     def run(self, observation, noise, u, temperature, legal=None, n_legal=None, hooks=None):
         """One move for all T games.  observation [T, obs] f32; noise [T,A] f64 (Dirichlet draws, injected like
         np.random.dirichlet in agent.py:172); u [T] f64 uniforms; temperature [T] f64.
         Returns (visits [T,A] i32, root_value [T] f64, minmax [T,2] f64, policy [T,A] f32, action [T] i32)."""
+        if hooks is None and self.native:
+            return self.run_native(observation, noise, u, temperature, legal, n_legal)
         pool, net, N = self.pool, self.network, self.N
         pool.reset()
         net.initial_inference_pool(observation, self.hidden, self.root_value_net, self.logits)

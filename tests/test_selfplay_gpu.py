@@ -213,3 +213,30 @@ def test_dropin_agent_stepwise_api():
         assert leaf.expanded() and leaf.visit_count == 1 and leaf.reward == float(np.float32(out.reward))
     assert root.visit_count == int(fx['N']) and root.value == float(fx['root_value'])
     np.testing.assert_array_equal([root.children[a].visit_count for a in legal], fx['root_visits'][legal])
+
+
+def test_native_move_equals_python_driven_move():
+    """mz_search_move (one C call per move) enqueues exactly the launches of the Python-driven LockstepSearch.run."""
+    import torch
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    T, N = 130, 9
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights('tictactoe', 4))
+    g = torch.Generator(device='cuda').manual_seed(1)
+    obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    noise = torch.distributions.Dirichlet(torch.ones(9, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    search = LockstepSearch(config, net, num_trees=T)
+
+    class NoHooks:
+        before_inference = after_inference = after_tree = staticmethod(lambda s: None)
+
+    a = [x.clone() for x in search.run(obs, noise, u, temp, hooks=NoHooks())]       # Python-driven
+    hidden_a = search.hidden.clone()
+    b = [x.clone() for x in search.run(obs, noise, u, temp)]                         # native
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(hidden_a, search.hidden)
