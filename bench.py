@@ -79,6 +79,8 @@ class SyntheticTreeMove:
             wl['T'], wl['A'], wl['N'], seed, wl['reward'], device)
         self.temperature = torch.ones(wl['T'], dtype=torch.float64, device=device)
         self.events = []
+        self.counters = self.pool.counters
+        self.trees_per_launch = wl['T']
 
     def run(self, timed_events=False):
         pool, N = self.pool, self.wl['N']
@@ -173,15 +175,22 @@ class NetworkMove:
     reference path of MCTSAgent.make_move, batched."""
     bound = 'mfma'
 
-    def __init__(self, wl, device, seed, world):
+    def __init__(self, wl, device, seed, world, lanes=1):
         from muzero_amd.games import cartpole, tictactoe
-        from muzero_amd.selfplay import LockstepSearch, TrajectoryGather
+        from muzero_amd.selfplay import LockstepSearch, PipelinedSearch, TrajectoryGather
         mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[wl['net']]
         self.wl = wl
         self.config = mod.make_config(num_simulations=wl['N'])
         self.net = self.config.network_config.network_class(self.config, seed=7)       # random-init (glorot) weights
-        self.search = LockstepSearch(self.config, self.net, num_trees=wl['T'], device=device)
-        self.pool = self.search.pool
+        self.lanes = lanes
+        if lanes > 1:
+            self.search = PipelinedSearch(self.config, self.net, num_trees=wl['T'], lanes=lanes, device=device)
+            self.counters = self.search.counters
+            self.trees_per_launch = self.search.lanes[0].T       # the events bracket lane 0's launches
+        else:
+            self.search = LockstepSearch(self.config, self.net, num_trees=wl['T'], device=device)
+            self.counters = self.search.pool.counters
+            self.trees_per_launch = wl['T']
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         T, A = wl['T'], wl['A']
@@ -272,6 +281,8 @@ def main():
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lanes', type=int, default=1,
+                    help='split the games of a GPU into this many lockstep lanes on separate HIP streams')
     ap.add_argument('--event-every', type=int, default=4,
                     help='record the per-kernel HIP events on every K-th timed step (each record costs stream time)')
     args = ap.parse_args()
@@ -293,14 +304,14 @@ def main():
         wl['T'] = args.trees
     with_net = wl['net'] is not None and not args.inject
     # per-rank seeds: every rank searches different games
-    move = NetworkMove(wl, device, 1234 + rank, world) if with_net else SyntheticTreeMove(wl, device, 1234 + rank)
+    move = NetworkMove(wl, device, 1234 + rank, world, args.lanes) if with_net else SyntheticTreeMove(wl, device, 1234 + rank)
 
     for _ in range(args.warmup):
         move.run()
     if with_net:
         move.finish()
     torch.cuda.synchronize()
-    c0 = move.pool.counters()
+    c0 = move.counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -314,7 +325,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    c1 = move.pool.counters()
+    c1 = move.counters()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -325,11 +336,11 @@ def main():
     assert sims_rank == args.steps * wl['T'] * wl['N'], (sims_rank, args.steps, wl['T'], wl['N'])
     total_sims = sims_rank * world
     mean_d = sum_d / sims_rank
-    tree_bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
+    tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
     if with_net:
         k1, k2, tree_s = move.hooks.durations()
-        flops_launch = wl['T'] * move.flops_per_eval
+        flops_launch = move.trees_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
         roofline = {'bound': 'mfma', 'kernel': move.dominant, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
@@ -353,7 +364,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if with_net else 'f64',
             'data': 'synthetic',
-            'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'actions': wl['A'],
+            'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'lanes_per_gpu': args.lanes if with_net else 1,
+                       'actions': wl['A'],
                        'simulations_per_move': wl['N'], 'network': network,
                        'sharding': f'{world} independent game shards (one rank per GPU)' +
                                    (', per-move all-gather of search statistics' if world > 1 and with_net else '')},

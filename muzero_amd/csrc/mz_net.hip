@@ -344,18 +344,17 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
 // and there is one weight set in registers instead of two), and the next activation tile is requested on the first
 // k-steps.  Issuing a stage's 80 KB up front instead stalls every wave of the workgroup on the vector-memory path.
 template <int KB>
-__device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BFrag& b, f32x16& acc, f32x16& acc2,
+__device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BFrag& b, f32x16& acc,
                                             const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
                                             float4 (&stg)[4]) {
     // LDS fragment ring, two k-steps ahead: the read issued here is consumed 8 MFMAs (512 cycles) later
     if (KB + 2 < 16) af[(KB + 2) % 3] = *reinterpret_cast<const float4*>(ap + (KB + 2) * 8);
     const float4 a = af[KB % 3];
     const float4 bv = b.v[KB];
-    // two independent accumulation chains: a dependent 32x32x2 chain alone issues every ~88 cycles, not 64
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc, 0, 0, 0);
 #ifndef MZ_EXP_NOVMEM
     b.v[KB] = wnext[KB * 256];
     if (KB < 4) stg[KB] = *reinterpret_cast<const float4*>(sptr[KB] + src);
@@ -376,12 +375,12 @@ __device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BF
 
 template <int... KB>
 __device__ __forceinline__ void mma_steps_pf(std::integer_sequence<int, KB...>, const float* ap, float4 (&af)[3], BFrag& b,
-                                             f32x16& acc, f32x16& acc2, const float4* __restrict__ wnext,
+                                             f32x16& acc, const float4* __restrict__ wnext,
                                              const float* const (&sptr)[4], int src, float4 (&stg)[4]) {
-    (mma_step_pf<KB>(ap, af, b, acc, acc2, wnext, sptr, src, stg), ...);
+    (mma_step_pf<KB>(ap, af, b, acc, wnext, sptr, src, stg), ...);
 }
 
-__device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& acc, f32x16& acc2, int lane,
+__device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& acc, int lane,
                                             const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
                                             float4 (&stg)[4]) {
     const float* ap = sA + (lane & 31) * kLd + 4 * (lane >> 5);
@@ -389,7 +388,7 @@ __device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& a
     af[0] = *reinterpret_cast<const float4*>(ap);
     af[1] = *reinterpret_cast<const float4*>(ap + 8);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two ring-priming reads come first
-    mma_steps_pf(std::make_integer_sequence<int, 16>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
+    mma_steps_pf(std::make_integer_sequence<int, 16>{}, ap, af, b, acc, wnext, sptr, src, stg);
 }
 
 // Recurrent inference, kernel A', uniform-cost jobs.  A job = 32 games x a group of board cells chosen so that every
@@ -475,7 +474,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
     commit(sTile[0]);
     __syncthreads();
 
-    f32x16 acc, acc2;
+    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
     int buf = 0;
 #pragma unroll 1
     for (int d = d0; d < d1; ++d) {
@@ -492,12 +493,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
                         : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
         const bool gather = has_next && nkind == 0;
         const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
-        if (kind != 0 || first_tap) {
+        if (kind == 1 || first_tap) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[r] = 0.f;
-                acc2[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
         float ab[16];
         if (kind == 0 && last_tap) {
@@ -506,11 +504,13 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
         }
-        mma_tile_pf(sA, bw, acc, acc2, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+        mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 2) accp = acc;
         if (kind == 0) {
             if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + ab[r], 0.f);
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + ab[r], 0.f);
             }
             if (gather) commit(sTile[buf ^ 1]);
             __syncthreads();
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             const float bn = w.dyn_dense_b[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + bn, 0.f);
+            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + bn, 0.f);
             __syncthreads();
             copy_out(sH, out_hidden + cell * 128, 1152);
             if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
@@ -526,13 +526,15 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
                 const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
                 if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
             }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201)
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
+            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = acc[r] + acc2[r];
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = accp[r];
+            }
             if (gather) commit(sTile[buf ^ 1]);
             __syncthreads();
             if (gather) buf ^= 1;
-            copy_out(sX, ppart + cell * 128, 1152);
+            if (!has_next) copy_out(sX, ppart + job * 128, 1152);
         }
     }
     if (trace && threadIdx.x == 0) {
@@ -622,7 +624,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
     commit(sTile[0]);
     __syncthreads();
 
-    f32x16 acc, acc2;
+    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
     int buf = 0;
     int seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0;      // diagnostic: setup / mma / epilogue+barrier / after-barrier [10 ns]
     long long t_last = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -648,12 +652,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
                         : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
         const bool gather = has_next && nkind == 0;
         const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
-        if (kind != 0 || first_tap) {
+        if (kind == 1 || first_tap) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[r] = 0.f;
-                acc2[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
         float ab[16];
         if (kind == 0 && last_tap) {
@@ -663,12 +664,14 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
             for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
         }
         MZ_SEG(seg0)
-        mma_tile_pf(sA, bw, acc, acc2, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+        mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 2) accp = acc;
         MZ_SEG(seg1)
         if (kind == 0) {
             if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + ab[r], 0.f);
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + ab[r], 0.f);
             }
             if (gather) commit(sTile[buf ^ 1]);
             __syncthreads();
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             const float bn = w.dyn_dense_b[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + acc2[r] + bn, 0.f);
+            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + bn, 0.f);
             __syncthreads();
             MZ_SEG(seg2)
             copy_out(sH, out_hidden + cell * 128, 1152);
@@ -686,14 +689,16 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
                 const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
                 if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
             }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201)
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
+            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = acc[r] + acc2[r];
+                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = accp[r];
+            }
             if (gather) commit(sTile[buf ^ 1]);
             __syncthreads();
             MZ_SEG(seg2)
             if (gather) buf ^= 1;
-            copy_out(sX, ppart + cell * 128, 1152);
+            if (!has_next) copy_out(sX, ppart + job * 128, 1152);
         }
         MZ_SEG(seg3)
     }
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
 }
 
 // Kernel B.  grid = ceil(B / (32*MT)).  parent_block only tells which rows are skipped.
-template <bool INITIAL, int MT>
+template <bool INITIAL, int MT, int NP>
 __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, const int* __restrict__ parent_block,
                                                             const float* __restrict__ ppart, const float* __restrict__ rpart,
                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
@@ -727,25 +732,30 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
     BFrag bw;
     load_b(bw, w.pred_dense_p, lane, wave);
     for (int i = tid; i < 1280; i += kThreads) sW[i] = i < 128 ? w.pred_value_w[i] : w.pred_policy_w[i - 128];
-    {   // relu(sum of the nine per-cell partial products + bias) (games/tictactoe.py:201)
+    {   // relu(sum of the NP partial products + bias) (games/tictactoe.py:201): NP = 9 per-cell partials (initial
+        // inference) or 4 per-job ones (recurrent); every load of the tile is issued before the first use
         const int c4 = tid & 31;
         const float4 bn = *reinterpret_cast<const float4*>(w.pred_conv_b + 4 * c4);
-#pragma unroll 2
-        for (int r = tid >> 5; r < ROWS; r += 8) {
-            const int b = row0 + r;
-            float4 s = bn;
-            if (b < B) {
-                const float4* p = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
+        constexpr int RPT = ROWS / 8;                  // rows per thread
+        float4 v[RPT][NP];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    const float4 v = p[c * 32];
-                    s.x += v.x;
-                    s.y += v.y;
-                    s.z += v.z;
-                    s.w += v.w;
-                }
+        for (int i = 0; i < RPT; ++i) {
+            const int b = min(row0 + (tid >> 5) + 8 * i, B - 1);
+            const float4* p = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) v[i][c] = p[c * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            float4 s = bn;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                s.x += v[i][c].x;
+                s.y += v[i][c].y;
+                s.z += v[i][c].z;
+                s.w += v[i][c].w;
             }
-            *reinterpret_cast<float4*>(sX + r * kLd + 4 * c4) =
+            *reinterpret_cast<float4*>(sX + ((tid >> 5) + 8 * i) * kLd + 4 * c4) =
                 make_float4(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f), fmaxf(s.z, 0.f), fmaxf(s.w, 0.f));
         }
     }
@@ -1361,8 +1371,8 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 31) / 32;
-        ttt_head_kernel<true, 1><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                          out_value, out_logits, out_value_raw);
+        ttt_head_kernel<true, 1, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                             out_value, out_logits, out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<true, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
@@ -1411,8 +1421,12 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                                                                    net->trace);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 31) / 32;
-        ttt_head_kernel<false, 1><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                           out_reward, out_value, out_logits, out_value_raw);
+        if (per_cell)
+            ttt_head_kernel<false, 1, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                                  out_reward, out_value, out_logits, out_value_raw);
+        else
+            ttt_head_kernel<false, 1, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                                  out_reward, out_value, out_logits, out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<false, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs, action,

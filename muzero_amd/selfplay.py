@@ -34,7 +34,9 @@ def shard_bounds(total_games: int, rank: int, world: int):
 
 
 class LockstepSearch:
-    def __init__(self, config, network, num_trees: int, device=None):
+    def __init__(self, config, network, num_trees: int, device=None, out=None):
+        """`out`: optional (visits, root_value, minmax, policy, action) tensors to write the results to (views of a
+        larger batch, see PipelinedSearch); allocated here when absent."""
         self.config = config
         self.network = network
         g, m = config.game_config, config.mcts_config
@@ -54,11 +56,16 @@ class LockstepSearch:
         self.value = torch.empty(self.T, **f32)
         self.frac = m.root_exploration_fraction
         i32 = dict(dtype=torch.int32, device=self.device)
-        self.out_visits = torch.empty(self.T, self.A, **i32)
-        self.out_root_value = torch.empty(self.T, dtype=torch.float64, device=self.device)
-        self.out_minmax = torch.empty(self.T, 2, dtype=torch.float64, device=self.device)
-        self.out_policy = torch.empty(self.T, self.A, **f32)
-        self.out_action = torch.empty(self.T, **i32)
+        if out is None:
+            out = (torch.empty(self.T, self.A, **i32), torch.empty(self.T, dtype=torch.float64, device=self.device),
+                   torch.empty(self.T, 2, dtype=torch.float64, device=self.device),
+                   torch.empty(self.T, self.A, **f32), torch.empty(self.T, **i32))
+        self.out_visits, self.out_root_value, self.out_minmax, self.out_policy, self.out_action = out
+        _check_tensor('out visits', self.out_visits, torch.int32, (self.T, self.A), self.device)
+        _check_tensor('out root_value', self.out_root_value, torch.float64, (self.T,), self.device)
+        _check_tensor('out minmax', self.out_minmax, torch.float64, (self.T, 2), self.device)
+        _check_tensor('out policy', self.out_policy, torch.float32, (self.T, self.A), self.device)
+        _check_tensor('out action', self.out_action, torch.int32, (self.T,), self.device)
         self.native = isinstance(network, Network)
 
     def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None):
@@ -115,6 +122,65 @@ class LockstepSearch:
         visits, root_value, minmax, policy = pool.root_stats()
         chosen = pool.select_action(u, temperature)
         return visits, root_value, minmax, policy, chosen
+
+
+class PipelinedSearch:
+    """T games searched as S independent lockstep lanes of T/S games, each lane on its own HIP stream.
+
+    Inside one lane a simulation is a strict chain (inference -> tree step -> inference ...), and the tree step and the
+    inference's head kernel are short latency-bound launches that leave the matrix cores idle.  With S > 1 lanes in
+    flight the hardware runs one lane's tree/head kernels underneath another lane's matrix kernel.  Lanes share
+    nothing but the weights (each has its own handle, scratch and tree pool), so the results are those of
+    LockstepSearch on the same games, bit for bit.  Same run()/run_native() signature."""
+
+    def __init__(self, config, network, num_trees: int, lanes: int = 2, device=None):
+        if not isinstance(network, Network):
+            raise MuZeroError('PipelinedSearch needs a HIP-backed muzero_amd.network.Network')
+        self.device = torch.device(device) if device is not None else network.device
+        self.T, self.A = int(num_trees), config.game_config.action_space_size
+        lanes = max(1, min(int(lanes), self.T))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.out_visits = torch.empty(self.T, self.A, **i32)
+        self.out_root_value = torch.empty(self.T, dtype=torch.float64, device=self.device)
+        self.out_minmax = torch.empty(self.T, 2, dtype=torch.float64, device=self.device)
+        self.out_policy = torch.empty(self.T, self.A, **f32)
+        self.out_action = torch.empty(self.T, **i32)
+        self.bounds = [shard_bounds(self.T, i, lanes) for i in range(lanes)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+        self.networks = [network] + [type(network)(config, weights=network.get_weights(),
+                                                   training_steps=network.training_steps(), device=self.device)
+                                     for _ in range(lanes - 1)]
+        self.lanes = []
+        for (lo, hi), net in zip(self.bounds, self.networks):
+            out = (self.out_visits[lo:hi], self.out_root_value[lo:hi], self.out_minmax[lo:hi],
+                   self.out_policy[lo:hi], self.out_action[lo:hi])
+            self.lanes.append(LockstepSearch(config, net, hi - lo, device=self.device, out=out))
+        self.pool = self.lanes[0].pool
+
+    def set_weights(self, flat, training_steps=None):
+        for net in self.networks:
+            net.set_weights(flat, training_steps)
+
+    def counters(self):
+        """(simulations, summed path lengths) over all lanes"""
+        per_lane = [lane.pool.counters() for lane in self.lanes]
+        return tuple(sum(c[i] for c in per_lane) for i in range(2))
+
+    def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None):
+        """`events` (measurement) are recorded on lane 0's stream."""
+        cur = torch.cuda.current_stream(self.device)
+        for i, ((lo, hi), lane, stream) in enumerate(zip(self.bounds, self.lanes, self.streams)):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                lane.run_native(observation[lo:hi], noise[lo:hi], u[lo:hi], temperature[lo:hi],
+                                None if legal is None else legal[lo:hi],
+                                None if n_legal is None else n_legal[lo:hi], events=events if i == 0 else None)
+        for stream in self.streams:
+            cur.wait_stream(stream)
+        return self.out_visits, self.out_root_value, self.out_minmax, self.out_policy, self.out_action
+
+    run = run_native
 
 
 class TrajectoryGather:

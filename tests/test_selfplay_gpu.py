@@ -240,3 +240,34 @@ def test_native_move_equals_python_driven_move():
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert torch.equal(hidden_a, search.hidden)
+
+
+@pytest.mark.parametrize('lanes', [2, 3])
+def test_pipelined_lanes_equal_one_lockstep_search(lanes):
+    """PipelinedSearch (games split into lanes on separate HIP streams) returns what one LockstepSearch over the same
+    games returns, bit for bit: lanes share nothing but the weights."""
+    import torch
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import LockstepSearch, PipelinedSearch
+    from oracle import net_oracle
+    T, N = 203, 11
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights('tictactoe', 5))
+    g = torch.Generator(device='cuda').manual_seed(3)
+    obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    noise = torch.distributions.Dirichlet(torch.ones(9, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    n_legal = torch.full((T,), 9, dtype=torch.int32, device='cuda')
+    n_legal[::17] = 0                                                     # some finished games
+    legal = torch.arange(9, dtype=torch.int32, device='cuda').repeat(T, 1).contiguous()
+    one = LockstepSearch(config, net, num_trees=T)
+    a = [x.clone() for x in one.run(obs, noise, u, temp, legal, n_legal)]
+    piped = PipelinedSearch(config, net, num_trees=T, lanes=lanes)
+    for _ in range(2):
+        b = piped.run(obs, noise, u, temp, legal, n_legal)
+        torch.cuda.synchronize()
+        active = (n_legal > 0)
+        for x, y in zip(a, b):
+            assert torch.equal(x[active], y[active])
+    assert piped.counters()[0] == 2 * int(active.sum()) * N
