@@ -227,6 +227,40 @@ typedef struct mz_move_io {
  * the loop, root statistics and action sampling -- about 3N+6 launches on the stream, no host synchronisation. */
 int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
 
+/* ---- batched environments on the device (the callers either side of a move) --------------- *
+ * State is caller-owned SoA over num_games games; every call enqueues one launch on `stream` (a hipStream_t).
+ * A finished game is frozen: step leaves it untouched and observe reports n_legal = 0, which mz_expand_roots
+ * and the inference entry points treat as "inactive".
+ *
+ * TicTacToe (reference games/tictactoe.py:71-148):
+ *   board [G,9] i8 (-1 empty, else the player id), to_play [G] i32, steps [G] i32, ended [G] i32 (0/1).
+ *   observe: out_observation [G,27] f32 = planes [board==0, board==1, to_play] stacked last (NHWC 3x3x3,
+ *            games/tictactoe.py:107-111); out_legal [G,9] i32 = empty cells ascending, padded with -1;
+ *            out_n_legal [G] i32 (0 once ended).  Any output may be NULL.
+ *   step:    plays action[g] for to_play[g]; out_reward [G] f32 = 1 on a winning move else 0; the game ends on a
+ *            win or after nine moves.  out_status [G] i32: 0 moved, 1 already ended, 2 illegal action (game left
+ *            untouched; the reference raises MuZeroEnvironmentError, games/tictactoe.py:122-123); any_illegal [1]
+ *            i32 is OR-ed with 1 when some game saw an illegal action.  out_reward/out_status/any_illegal may be NULL. */
+int mz_env_ttt_reset(void* stream, int32_t num_games, int8_t* board, int32_t* to_play, int32_t* steps, int32_t* ended);
+int mz_env_ttt_observe(void* stream, int32_t num_games, const int8_t* board, const int32_t* to_play,
+                       const int32_t* ended, float* out_observation, int32_t* out_legal, int32_t* out_n_legal);
+int mz_env_ttt_step(void* stream, int32_t num_games, int8_t* board, int32_t* to_play, int32_t* steps, int32_t* ended,
+                    const int32_t* action, float* out_reward, int32_t* out_status, int32_t* any_illegal);
+
+/* CartPole-v1 (reference environment.py:44-63 wraps gym.make('CartPole-v1'); gym is third-party and absent, so
+ * its classic-control equations are restated: Euler step tau = 0.02, force +-10, episode ends at |x| > 2.4,
+ * |theta| > 12 degrees or 500 steps; reward 1 per step).
+ *   state [G,4] f64 (x, x_dot, theta, theta_dot), steps [G] i32, ended [G] i32;
+ *   reset copies initial_state [G,4] f64 (the caller draws U(-0.05, 0.05) like gym's reset);
+ *   observe: out_observation [G,4] f32 (environment.py:59), out_legal [G,2] = {0,1}, out_n_legal = 2 or 0;
+ *   step: as above with actions {0,1}. */
+int mz_env_cartpole_reset(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
+                          const double* initial_state);
+int mz_env_cartpole_observe(void* stream, int32_t num_games, const double* state, const int32_t* ended,
+                            float* out_observation, int32_t* out_legal, int32_t* out_n_legal);
+int mz_env_cartpole_step(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
+                         const int32_t* action, float* out_reward, int32_t* out_status, int32_t* any_illegal);
+
 #ifdef __cplusplus
 }
 #endif

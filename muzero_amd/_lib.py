@@ -65,6 +65,15 @@ PROTOTYPES = {
     'mz_search_move': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(MoveIO)]),
     'mz_infer_recurrent': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_ttt_reset': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_ttt_observe': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
+    'mz_env_ttt_step': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    'mz_env_cartpole_reset': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_cartpole_observe': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_cartpole_step': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -31,6 +31,10 @@
 #include <utility>
 #include <vector>
 
+#ifndef MZ_EXP_PRIO
+#define MZ_EXP_PRIO 0
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -417,6 +421,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
     // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+#if MZ_EXP_PRIO == 1
+    if ((bi >> 5) & 1) __builtin_amdgcn_s_setprio(3);
+#endif
     const int row0 = rb * ROWS;
     const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
     const int n = wave * 32 + (lane & 31);
@@ -505,7 +512,17 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
             for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
         }
         if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+#if MZ_EXP_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#elif MZ_EXP_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+#if MZ_EXP_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#elif MZ_EXP_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (kind == 2) accp = acc;
         if (kind == 0) {
             if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
@@ -536,6 +553,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
             if (gather) buf ^= 1;
             if (!has_next) copy_out(sX, ppart + job * 128, 1152);
         }
+#ifdef MZ_EXP_FENCE
+        if ((d % MZ_EXP_FENCE) == MZ_EXP_FENCE - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+#endif
     }
     if (trace && threadIdx.x == 0) {
         long long* tr = trace + 8 * (size_t)blockIdx.x;
@@ -561,6 +584,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
     __shared__ int sAct[ROWS];
     __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
     const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long c_start = trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
     const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -713,6 +737,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
         tr[4] = ((long long)t_pro << 32) | (unsigned)seg0;
         tr[5] = ((long long)seg1 << 32) | (unsigned)seg2;
         tr[6] = seg3;
+        tr[7] = (long long)__builtin_amdgcn_s_memtime() - c_start;      // shader-clock ticks (DVFS check)
     }
 }
 

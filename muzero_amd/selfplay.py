@@ -183,6 +183,145 @@ class PipelinedSearch:
     run = run_native
 
 
+class BatchedHistory:
+    """GameHistory (game.py:8-41) of G lockstep games as padded device tensors, M = move capacity:
+
+        observations [M+1, G, obs] f32 | to_plays [M+1, G] i32 | actions [M, G] i32 | rewards [M, G] f32 |
+        root_values [M, G] f64 | policies [M, G, A] f32 | lengths [G] i32
+
+    Entries at move index >= lengths[g] are padding.  This is also the block the ranks exchange when games finish
+    (`all_gather`): fixed-size, so one all-gather per field and no size negotiation."""
+    FIELDS = ('observations', 'to_plays', 'actions', 'rewards', 'root_values', 'policies', 'lengths')
+
+    def __init__(self, max_moves: int, num_games: int, observation_shape, num_actions: int, device) -> None:
+        self.M, self.G, self.A = int(max_moves), int(num_games), int(num_actions)
+        self.observation_shape = tuple(observation_shape)
+        obs = 1
+        for d in self.observation_shape:
+            obs *= int(d)
+        z = lambda shape, dtype: torch.zeros(*shape, dtype=dtype, device=device)
+        self.observations = z((self.M + 1, self.G, obs), torch.float32)
+        self.to_plays = z((self.M + 1, self.G), torch.int32)
+        self.actions = z((self.M, self.G), torch.int32)
+        self.rewards = z((self.M, self.G), torch.float32)
+        self.root_values = z((self.M, self.G), torch.float64)
+        self.policies = z((self.M, self.G, self.A), torch.float32)
+        self.lengths = z((self.G,), torch.int32)
+        self.metadata = {}
+
+    def to_game_histories(self):
+        """-> list of G `game.GameHistory` with the reference's fields (host copies; synchronises)."""
+        from .game import GameHistory
+        host = {f: getattr(self, f).cpu().numpy() for f in self.FIELDS}
+        games = []
+        for g in range(self.G):
+            n = int(host['lengths'][g])
+            h = GameHistory()
+            h.observations = [host['observations'][m, g].reshape(self.observation_shape) for m in range(n + 1)]
+            h.to_plays = [int(x) for x in host['to_plays'][:n + 1, g]]
+            h.actions = [int(x) for x in host['actions'][:n, g]]
+            h.rewards = [float(x) for x in host['rewards'][:n, g]]
+            h.root_values = [float(x) for x in host['root_values'][:n, g]]
+            h.policies = [host['policies'][m, g].copy() for m in range(n)]
+            h.metadata.update(self.metadata)
+            games.append(h)
+        return games
+
+    def all_gather(self, group=None):
+        """Every rank's finished games, concatenated along the game axis in rank order (RCCL over xGMI on GPUs,
+        gloo in the CPU tests).  All ranks must hold the same M and G."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        out = BatchedHistory(self.M, self.G * world, self.observation_shape, self.A, self.lengths.device)
+        out.metadata = dict(self.metadata)
+        for f in self.FIELDS:
+            mine = getattr(self, f).contiguous()
+            if world == 1:
+                getattr(out, f).copy_(mine)
+                continue
+            parts = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(parts.view(-1), mine.view(-1), group=group)
+            if f == 'lengths':
+                out.lengths.copy_(parts.reshape(-1))
+            else:       # [world, M(+1), G, ...] -> [M(+1), world*G, ...]
+                moved = parts.movedim(0, 1)
+                getattr(out, f).copy_(moved.reshape(moved.shape[0], world * self.G, *moved.shape[3:]))
+        return out
+
+
+class SelfPlayEngine:
+    """Agent.play_game (agent.py:31-44) for G games at once: every move is one `observe` launch, one lockstep search
+    (`mz_search_move`) and one `step` launch; observations, search statistics and rewards are recorded into a
+    BatchedHistory on the device.  Randomness (Dirichlet noise, action sampling) is drawn on the device from a
+    torch generator -- the single-game MCTSAgent is the path that reproduces the reference's host RNG stream."""
+
+    def __init__(self, config, network, num_games: int, vector_env=None, device=None, lanes: int = 1,
+                 seed: Optional[int] = None):
+        from . import vector_env as venv
+        self.config, self.network = config, network
+        self.device = torch.device(device) if device is not None else network.device
+        self.G = int(num_games)
+        if vector_env is None:
+            classes = {'TicTacToe': venv.TicTacToeVectorEnv, 'CartPole': venv.CartPoleVectorEnv}
+            name = config.game_config.name
+            if name not in classes:
+                raise MuZeroError(f'no batched environment for game {name!r}: pass vector_env=')
+            vector_env = classes[name](self.G, device=self.device)
+        self.env = vector_env
+        if self.env.G != self.G or self.env.action_space_size != config.game_config.action_space_size:
+            raise MuZeroError('vector_env does not match num_games / the action space of the config')
+        if lanes > 1:
+            self.search = PipelinedSearch(config, network, self.G, lanes=lanes, device=self.device)
+        else:
+            self.search = LockstepSearch(config, network, self.G, device=self.device)
+        self.A = config.game_config.action_space_size
+        self.generator = torch.Generator(device=self.device)
+        if seed is not None:
+            self.generator.manual_seed(seed)
+        self.alpha = torch.full((self.G, self.A), float(config.mcts_config.root_dirichlet_alpha), dtype=torch.float64,
+                                device=self.device)
+        self.slot = torch.arange(self.A, device=self.device, dtype=torch.int32).unsqueeze(0)
+        self.temperature = torch.empty(self.G, dtype=torch.float64, device=self.device)
+
+    def _dirichlet(self, n_legal):
+        """noise[g, :n_legal[g]] ~ Dirichlet(alpha) (agent.py:172), zeros elsewhere: normalised Gamma(alpha, 1) draws."""
+        gamma = torch._standard_gamma(self.alpha, generator=self.generator)
+        gamma = torch.where(self.slot < n_legal.unsqueeze(1), gamma, torch.zeros_like(gamma))
+        total = gamma.sum(dim=1, keepdim=True)
+        return torch.where(total > 0, gamma / total, torch.zeros_like(gamma)).contiguous()
+
+    def play_games(self, max_moves: Optional[int] = None, check_every: int = 1) -> BatchedHistory:
+        env, cfg = self.env, self.config
+        M = int(max_moves if max_moves is not None else cfg.mcts_config.max_moves)
+        hist = BatchedHistory(M, self.G, self.network.OBSERVATION_SHAPE, self.A, self.device)
+        env.reset()
+        steps = self.network.training_steps()
+        played = 0
+        for m in range(M):
+            obs, legal, n_legal = env.observe()
+            hist.observations[m].copy_(obs)
+            hist.to_plays[m].copy_(env.to_play)
+            noise = self._dirichlet(n_legal)
+            u = torch.rand(self.G, dtype=torch.float64, device=self.device, generator=self.generator)
+            self.temperature.fill_(float(cfg.visit_softmax_temperature_fn(num_moves=m, training_steps=steps)))
+            _visits, root_value, _minmax, policy, action = self.search.run(obs, noise, u, self.temperature, legal,
+                                                                           n_legal)
+            hist.actions[m].copy_(action)
+            hist.root_values[m].copy_(root_value)
+            hist.policies[m].copy_(policy)
+            hist.rewards[m].copy_(env.step(action))
+            played = m + 1
+            if played % check_every == 0 and env.all_ended():
+                break
+        obs, _, _ = env.observe()
+        hist.observations[played].copy_(obs)
+        hist.to_plays[played].copy_(env.to_play)
+        hist.lengths.copy_(env.steps)
+        env.check_illegal()
+        hist.metadata = {'network_id': str(steps), 'moves_played': played}
+        return hist
+
+
 class TrajectoryGather:
     """All-gather of per-move search statistics over the ranks (RCCL over xGMI on GPUs, gloo in CPU tests).
 

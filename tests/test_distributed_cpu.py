@@ -70,3 +70,52 @@ def test_shard_bounds_cover_all_games():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def history_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from muzero_amd.selfplay import BatchedHistory
+    h = make_history(rank)
+    full = h.all_gather()
+    torch.save({f: getattr(full, f) for f in BatchedHistory.FIELDS}, os.path.join(out_dir, f'hist{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def make_history(rank, M=5, G=3, A=4):
+    from muzero_amd.selfplay import BatchedHistory
+    g = torch.Generator().manual_seed(100 + rank)
+    h = BatchedHistory(M, G, (2, 3), A, torch.device('cpu'))
+    h.observations.copy_(torch.rand(h.observations.shape, generator=g))
+    h.to_plays.copy_(torch.randint(0, 2, h.to_plays.shape, generator=g))
+    h.actions.copy_(torch.randint(0, A, h.actions.shape, generator=g))
+    h.rewards.copy_(torch.rand(h.rewards.shape, generator=g))
+    h.root_values.copy_(torch.rand(h.root_values.shape, generator=g, dtype=torch.float64))
+    h.policies.copy_(torch.rand(h.policies.shape, generator=g))
+    h.lengths.copy_(torch.randint(1, M + 1, h.lengths.shape, generator=g))
+    return h
+
+
+def test_finished_games_all_gather_two_ranks(tmp_path):
+    """The one exchange of the path: every rank ends up with every rank's games, in rank order."""
+    world, port = 2, 31500 + os.getpid() % 2000
+    mp.spawn(history_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [make_history(r) for r in range(world)]
+    G = parts[0].G
+    for rank in range(world):
+        got = torch.load(tmp_path / f'hist{rank}.pt', weights_only=True)
+        for r, p in enumerate(parts):
+            assert torch.equal(got['lengths'][r * G:(r + 1) * G], p.lengths)
+            for f in ('observations', 'to_plays', 'actions', 'rewards', 'root_values', 'policies'):
+                assert torch.equal(got[f][:, r * G:(r + 1) * G], getattr(p, f)), f
+    # the gathered block converts to the reference's GameHistory field set
+    from muzero_amd.selfplay import BatchedHistory
+    whole = BatchedHistory(parts[0].M, G * world, (2, 3), parts[0].A, torch.device('cpu'))
+    for f in BatchedHistory.FIELDS:
+        getattr(whole, f).copy_(got[f])
+    games = whole.to_game_histories()
+    assert len(games) == G * world
+    for i, h in enumerate(games):
+        n = int(got['lengths'][i])
+        assert len(h) == n and len(h.observations) == n + 1 and h.observations[0].shape == (2, 3)
+        assert h.actions == got['actions'][:n, i].tolist() and len(h.policies) == n == len(h.root_values)

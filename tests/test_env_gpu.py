@@ -1,0 +1,156 @@
+"""Batched device environments and the lockstep self-play loop against the single-game host
+classes, which follow the reference's environment semantics (games/tictactoe.py:71-148, environment.py:44-63)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tictactoe_vector_env_matches_host_env():
+    import torch
+    from muzero_amd.environment import TicTacToeEnvironment
+    from muzero_amd.vector_env import TicTacToeVectorEnv
+    G = 300
+    rng = np.random.default_rng(11)
+    venv = TicTacToeVectorEnv(G)
+    assert venv.all_ended()                                   # nothing to play before reset
+    venv.reset()
+    hosts = [TicTacToeEnvironment() for _ in range(G)]
+    states = [h.reset() for h in hosts]
+    done = [False] * G
+    for move in range(10):
+        obs, legal, n_legal = (x.cpu().numpy().copy() for x in venv.observe())
+        to_play = venv.to_play.cpu().numpy()
+        for g in range(G):
+            np.testing.assert_array_equal(obs[g].reshape(3, 3, 3), states[g].observation)
+            assert to_play[g] == states[g].to_play
+            want = states[g].legal_actions
+            assert n_legal[g] == len(want) and list(legal[g, :len(want)]) == want and (legal[g, len(want):] == -1).all()
+        if all(done):
+            break
+        action = np.full(G, -1, np.int32)
+        for g in range(G):
+            if not done[g]:
+                action[g] = rng.choice(states[g].legal_actions)
+        reward = venv.step(torch.from_numpy(action).cuda()).cpu().numpy().copy()
+        status, ended = venv.status.cpu().numpy(), venv.ended.cpu().numpy()
+        for g in range(G):
+            if done[g]:
+                assert status[g] == 1 and reward[g] == 0.0
+                continue
+            states[g], r, d, _ = hosts[g].step(int(action[g]))
+            done[g] = d
+            assert status[g] == 0 and reward[g] == np.float32(r) and bool(ended[g]) == d
+    assert all(done) and venv.all_ended()
+    venv.check_illegal()                                      # no illegal action was played
+    np.testing.assert_array_equal(venv.steps.cpu().numpy(), [h.steps for h in hosts])
+
+
+def test_tictactoe_vector_env_rejects_illegal_actions():
+    import torch
+    from muzero_amd.exceptions import MuZeroEnvironmentError
+    from muzero_amd.vector_env import TicTacToeVectorEnv
+    venv = TicTacToeVectorEnv(4)
+    venv.reset()
+    venv.step(torch.tensor([0, 4, 8, 2], dtype=torch.int32, device='cuda'))
+    before = venv.board.clone()
+    venv.step(torch.tensor([0, 9, -1, 3], dtype=torch.int32, device='cuda'))     # occupied, out of range x2, legal
+    assert venv.status.tolist() == [2, 2, 2, 0]
+    assert torch.equal(venv.board[:3], before[:3]) and venv.steps.tolist() == [1, 1, 1, 2]
+    with pytest.raises(MuZeroEnvironmentError):
+        venv.check_illegal()
+
+
+def test_cartpole_vector_env_matches_host_restatement():
+    import torch
+    from muzero_amd.environment import CartPoleEnvironment
+    from muzero_amd.vector_env import CartPoleVectorEnv
+    G, rng = 64, np.random.default_rng(3)
+    venv = CartPoleVectorEnv(G, seed=5)
+    venv.reset()
+    init = venv.state.cpu().numpy().copy()
+    assert (np.abs(init) <= 0.05).all() and len(np.unique(init)) > G
+    hosts = [CartPoleEnvironment() for _ in range(G)]
+    for g, h in enumerate(hosts):
+        h.reset()
+        h.state = init[g].copy()
+    done = np.zeros(G, bool)
+    for move in range(200):
+        obs, legal, n_legal = (x.cpu().numpy().copy() for x in venv.observe())
+        assert (n_legal == np.where(done, 0, 2)).all() and (legal == [0, 1]).all()
+        if done.all():
+            break
+        # a biased policy so that episodes end at different times
+        action = (rng.random(G) < 0.8).astype(np.int32)
+        reward = venv.step(torch.from_numpy(action).cuda()).cpu().numpy().copy()
+        state, ended = venv.state.cpu().numpy(), venv.ended.cpu().numpy().astype(bool)
+        for g in range(G):
+            if done[g]:
+                assert reward[g] == 0.0
+                continue
+            st, r, d, _ = hosts[g].step(int(action[g]))
+            # fp64 state: same operation order; device sin/cos differ from glibc by a few ulp at most
+            np.testing.assert_allclose(state[g], hosts[g].state, rtol=1e-12, atol=1e-13)
+            assert reward[g] == 1.0 and ended[g] == d
+            done[g] = d
+    assert done.all()
+
+
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_selfplay_engine_plays_legal_complete_tictactoe_games(lanes):
+    """The batched play_game loop: every recorded game replays on the host environment to the same rewards,
+    players, observations and length; search statistics are well-formed."""
+    import torch
+    from muzero_amd.environment import TicTacToeEnvironment
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import SelfPlayEngine
+    G, N = 150, 6
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=3)
+    engine = SelfPlayEngine(config, net, G, seed=17, lanes=lanes)
+    hist = engine.play_games()
+    games = hist.to_game_histories()
+    assert len(games) == G
+    lengths = hist.lengths.cpu().numpy()
+    assert lengths.min() >= 5 and lengths.max() <= 9 and len(set(lengths.tolist())) > 1
+    for g, h in enumerate(games):
+        env = TicTacToeEnvironment()
+        state = env.reset()
+        assert len(h) == lengths[g] and len(h.observations) == len(h) + 1 == len(h.to_plays)
+        for m, a in enumerate(h.actions):
+            np.testing.assert_array_equal(h.observations[m], state.observation)
+            assert h.to_plays[m] == state.to_play and a in state.legal_actions
+            pol = h.policies[m]
+            assert pol.shape == (9,) and abs(float(pol.sum()) - 1.0) < 1e-6
+            assert (pol[[x for x in range(9) if x not in state.legal_actions]] == 0).all()
+            assert (np.round(pol * N) == pol * N).all() or np.allclose(np.round(pol * N), pol * N, atol=1e-5)
+            assert -1.0 <= h.root_values[m] <= 1.0
+            state, r, done, _ = env.step(a)
+            assert h.rewards[m] == r
+        assert done
+        np.testing.assert_array_equal(h.observations[-1], state.observation)
+        assert h.to_plays[-1] == state.to_play
+        assert h.metadata['network_id'] == '0'
+    # a second batch re-uses the engine; a different random stream gives different games
+    again = engine.play_games()
+    assert not torch.equal(again.actions, hist.actions)
+
+
+def test_selfplay_engine_cartpole_short_episodes():
+    import torch
+    from muzero_amd.games import cartpole
+    from muzero_amd.selfplay import SelfPlayEngine
+    G, N, M = 40, 5, 12
+    config = cartpole.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=1)
+    engine = SelfPlayEngine(config, net, G, seed=2)
+    hist = engine.play_games(max_moves=M)
+    lengths = hist.lengths.cpu().numpy()
+    assert (lengths >= 1).all() and (lengths <= M).all()
+    acts = hist.actions.cpu().numpy()
+    rew = hist.rewards.cpu().numpy()
+    for g in range(G):
+        assert set(acts[:lengths[g], g].tolist()) <= {0, 1}
+        assert (rew[:lengths[g], g] == 1.0).all() and (rew[lengths[g]:, g] == 0.0).all()
+    pol = hist.policies.cpu().numpy()
+    np.testing.assert_allclose(pol[0].sum(-1), 1.0, atol=1e-6)

@@ -12,8 +12,15 @@ r = torch.empty(T, device='cuda'); v = torch.empty(T, device='cuda'); lg = torch
 rows = int(os.environ.get('MZ_TILE_ROWS', '64'))
 nwg = 9 * (T // rows) if os.environ.get('MZ_CELL_KERNEL') else 32 * ((T // 32 + 7) // 8)
 trace = torch.zeros(nwg * 8, dtype=torch.int64, device='cuda')
+import time
+warm = float(os.environ.get('MZ_WARM_SECONDS', '0'))
+t_w = time.time()
 for _ in range(3):
     net.recurrent_inference_pool(hid, pb, act, 1, r, v, lg)
+while time.time() - t_w < warm:            # sustained load first: the chip lowers its clock under load
+    for _ in range(200):
+        net.recurrent_inference_pool(hid, pb, act, 1, r, v, lg)
+    torch.cuda.synchronize()
 net._lib.mzdbg_net_set_trace(net._h, ctypes.c_void_p(trace.data_ptr()))
 net.recurrent_inference_pool(hid, pb, act, 1, r, v, lg)
 torch.cuda.synchronize()
@@ -24,6 +31,9 @@ start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0        # microsecond
 hw = t[:, 2] & 0xffffffff; xcc = (t[:, 2] >> 32) & 0xf; mma = seg[:, 2]
 cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
 print('kernel span us', end.max(), 'n wg', nwg)
+if not os.environ.get('MZ_CELL_KERNEL'):
+    ghz = t[:, 7] / ((t[:, 1] - t[:, 0]) * 10.0)
+    print('in-kernel shader clock GHz: median %.3f min %.3f max %.3f' % (np.median(ghz), ghz.min(), ghz.max()))
 if not os.environ.get('MZ_CELL_KERNEL'):
     sg = np.stack([t[:, 4] >> 32, t[:, 4] & 0xffffffff, t[:, 5] >> 32, t[:, 5] & 0xffffffff, t[:, 6]], 1) / 100.0
     for j in range(4):
