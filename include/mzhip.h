@@ -261,6 +261,30 @@ int mz_env_cartpole_observe(void* stream, int32_t num_games, const double* state
 int mz_env_cartpole_step(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
                          const int32_t* action, float* out_reward, int32_t* out_status, int32_t* any_illegal);
 
+/* ---- replay-side training targets (the step after the path) -------------------------------- *
+ * ReplayBuffer.preprocess_history + compute_target_value (reference replay_buffer.py:66-99) for G finished games
+ * held as padded move-major arrays (muzero_amd.selfplay.BatchedHistory), M = move capacity, K = num_unroll_steps:
+ *   lengths [G] i32; actions [M,G] i32; rewards [M,G] f32; root_values [M,G] f64; policies [M,G,A] f32;
+ *   random_actions [G,K] i32: the random actions appended past the terminal state (random.randrange in the
+ *       reference, replay_buffer.py:78; injected);
+ *   discount_powers f64, max(td_steps, M)+1 entries: effective_discount**i evaluated by the host (Python pow);
+ *   out_extended_actions [M+K,G] i32; out_target_rewards [M+K,G,Dr] f32; out_target_values [M+K+1,G,Dv] f32;
+ *   out_target_policies [M+K+1,G,A] f32 (uniform rows past the end); out_total_value [G] f64 or NULL.
+ *   Dr/Dv = 1 for a scalar head (support 0) else support+1 (two-hot, utils.py:138-143 with config.py:34-36 bounds).
+ * Entries of game g beyond its own length (+K, +K+1) are zero padding. */
+typedef struct mz_replay_config {
+    int32_t num_games, max_moves, num_actions, num_unroll_steps, td_steps;
+    int32_t value_support;      /* 0 = ScalarConfig.support_size None */
+    int32_t reward_support;
+    int32_t reserved;
+    double value_min, value_max, reward_min, reward_max;   /* KnownBounds.endpoints(); used only with a support */
+} mz_replay_config_t;
+int mz_replay_targets(void* stream, const mz_replay_config_t* config, const int32_t* lengths, const int32_t* actions,
+                      const float* rewards, const double* root_values, const float* policies,
+                      const int32_t* random_actions, const double* discount_powers, int32_t* out_extended_actions,
+                      float* out_target_rewards, float* out_target_values, float* out_target_policies,
+                      double* out_total_value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,13 @@ class MoveIO(ctypes.Structure):
                 ('out_action', c_void_p), ('events', c_void_p)]
 
 
+class ReplayConfig(ctypes.Structure):
+    """mz_replay_config_t"""
+    _fields_ = [('num_games', c_int32), ('max_moves', c_int32), ('num_actions', c_int32), ('num_unroll_steps', c_int32),
+                ('td_steps', c_int32), ('value_support', c_int32), ('reward_support', c_int32), ('reserved', c_int32),
+                ('value_min', c_double), ('value_max', c_double), ('reward_min', c_double), ('reward_max', c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/mzhip.h declares
 PROTOTYPES = {
     'mz_last_error': (ctypes.c_char_p, []),
@@ -72,6 +79,7 @@ PROTOTYPES = {
                                        c_void_p, c_void_p]),
     'mz_env_cartpole_reset': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_env_cartpole_observe': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_replay_targets': (ctypes.c_int, [c_void_p, ctypes.POINTER(ReplayConfig)] + [c_void_p] * 12),
     'mz_env_cartpole_step': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
 }

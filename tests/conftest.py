@@ -26,7 +26,8 @@ def load_golden(name):
         return {k: data[k] for k in data.files}
 
 
-TREE_FIXTURES = [n for n in golden_names() if not n.startswith('ttt_game')]
+TREE_FIXTURES = [n for n in golden_names() if not n.startswith(('ttt_game', 'replay_'))]
+REPLAY_FIXTURES = golden_names('replay_')
 GAME_FIXTURES = golden_names('ttt_game')
 
 
