@@ -169,6 +169,49 @@ class Network:
                 raise MuZeroError('checkpoint is for a different network kind')
             self.set_weights(data['weights'], int(data['steps']))
 
+    # ------------------------------------------------------------------ weight hand-off
+    WEIGHTS_FILE = 'weights.npz'
+
+    def save_version(self, models_path: str) -> str:
+        """Publish the current weights as version `training_steps()`: `<models_path>/<steps>/weights.npz`, the
+        versioned-directory convention of Network.save_tfx_models (network.py:262-266, called from training.py:62-63)
+        that TF-Serving watches.  Written to a temporary directory and renamed, so a reader never sees half a file."""
+        import os
+        import tempfile
+        os.makedirs(models_path, exist_ok=True)
+        final = os.path.join(models_path, str(self.steps))
+        tmp = tempfile.mkdtemp(prefix='.tmp_', dir=models_path)
+        np.savez(os.path.join(tmp, self.WEIGHTS_FILE), weights=self._weights, steps=np.int64(self.steps),
+                 kind=np.int32(self.KIND))
+        if os.path.isdir(final):                      # same version published twice: keep the first
+            import shutil
+            shutil.rmtree(tmp)
+        else:
+            os.rename(tmp, final)
+        return final
+
+    @classmethod
+    def available_versions(cls, models_path: str) -> List[int]:
+        import os
+        if not os.path.isdir(models_path):
+            return []
+        return sorted(int(d) for d in os.listdir(models_path)
+                      if d.isdigit() and os.path.isfile(os.path.join(models_path, d, cls.WEIGHTS_FILE)))
+
+    def load_latest(self, models_path: str) -> bool:
+        """Hot-reload: upload the highest published version if it is newer than `training_steps()` (what a
+        RemoteNetwork observes as response.model_spec.version, network_services.py:57).  -> True if weights changed.
+        Call it between moves or games: the upload is ordered on the network's stream."""
+        import os
+        versions = self.available_versions(models_path)
+        if not versions or versions[-1] <= self.steps:
+            return False
+        with np.load(os.path.join(models_path, str(versions[-1]), self.WEIGHTS_FILE), allow_pickle=False) as data:
+            if int(data['kind']) != self.KIND:
+                raise MuZeroError('published weights are for a different network kind')
+            self.set_weights(data['weights'], int(data['steps']))
+        return True
+
     def close(self):
         if self._h is not None:
             self._lib.mz_net_destroy(self._h)

@@ -256,9 +256,11 @@ class SelfPlayEngine:
     torch generator -- the single-game MCTSAgent is the path that reproduces the reference's host RNG stream."""
 
     def __init__(self, config, network, num_games: int, vector_env=None, device=None, lanes: int = 1,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, models_path: Optional[str] = None):
+        """models_path: directory of published weight versions (Network.save_version); the newest one is hot-loaded
+        before every batch of games, like an agent picking up TF-Serving's latest model version."""
         from . import vector_env as venv
-        self.config, self.network = config, network
+        self.config, self.network, self.models_path = config, network, models_path
         self.device = torch.device(device) if device is not None else network.device
         self.G = int(num_games)
         if vector_env is None:
@@ -294,6 +296,9 @@ class SelfPlayEngine:
         env, cfg = self.env, self.config
         M = int(max_moves if max_moves is not None else cfg.mcts_config.max_moves)
         hist = BatchedHistory(M, self.G, self.network.OBSERVATION_SHAPE, self.A, self.device)
+        if self.models_path and self.network.load_latest(self.models_path) and isinstance(self.search, PipelinedSearch):
+            for replica in self.search.networks[1:]:
+                replica.set_weights(self.network.get_weights(), self.network.training_steps())
         env.reset()
         steps = self.network.training_steps()
         played = 0

@@ -154,3 +154,20 @@ def test_selfplay_engine_cartpole_short_episodes():
         assert (rew[:lengths[g], g] == 1.0).all() and (rew[lengths[g]:, g] == 0.0).all()
     pol = hist.policies.cpu().numpy()
     np.testing.assert_allclose(pol[0].sum(-1), 1.0, atol=1e-6)
+
+
+def test_selfplay_engine_hot_reloads_published_weights(tmp_path):
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import SelfPlayEngine
+    config = tictactoe.make_config(num_simulations=4)
+    cls = config.network_config.network_class
+    net = cls(config, seed=1)
+    models = str(tmp_path / 'models')
+    engine = SelfPlayEngine(config, net, 32, seed=4, lanes=2, models_path=models)
+    assert engine.play_games().metadata['network_id'] == '0'
+    cls(config, seed=2, training_steps=250).save_version(models)
+    hist = engine.play_games()
+    assert hist.metadata['network_id'] == '250' and net.training_steps() == 250
+    assert all(n.training_steps() == 250 for n in engine.search.networks)
+    import numpy as np
+    np.testing.assert_array_equal(engine.search.networks[1].get_weights(), cls(config, seed=2).get_weights())

@@ -129,3 +129,38 @@ def test_weight_count_and_checkpoint_round_trip(tmp_path):
     np.testing.assert_array_equal(other.initial_inference(obs).batch_policy_logits.cpu().numpy(), before)
     with pytest.raises(MuZeroError):
         TicTacToeNetwork(config=None, weights=np.zeros(10, np.float32))
+
+
+def test_versioned_weight_handoff(tmp_path):
+    """save_version / load_latest: the versioned-directory hand-off of network.py:262-266 + training.py:62-63; the
+    reader picks the highest complete version newer than its own and its outputs change with it."""
+    import torch
+    from muzero_amd.games import cartpole
+    from oracle import net_oracle
+    config = cartpole.make_config(num_simulations=4)
+    cls = config.network_config.network_class
+    trainer = cls(config, weights=net_oracle.random_weights('cartpole', 1), training_steps=0)
+    actor = cls(config, weights=net_oracle.random_weights('cartpole', 1), training_steps=0)
+    obs = torch.tensor([[0.01, -0.02, 0.03, 0.04]], device='cuda')
+    before = actor.initial_inference(obs).batch_policy_logits.clone()
+    models = str(tmp_path / 'models')
+    assert cls.available_versions(models) == [] and not actor.load_latest(models)
+    trainer.save_version(models)                                        # version 0: not newer
+    assert not actor.load_latest(models)
+    trainer.set_weights(net_oracle.random_weights('cartpole', 2), training_steps=500)
+    trainer.save_version(models)
+    trainer.set_weights(net_oracle.random_weights('cartpole', 3), training_steps=1000)
+    trainer.save_version(models)
+    (tmp_path / 'models' / '2000').mkdir()                              # incomplete version: no weights file yet
+    (tmp_path / 'models' / 'notes').mkdir()
+    assert cls.available_versions(models) == [0, 500, 1000]
+    assert actor.load_latest(models) and actor.training_steps() == 1000
+    after = actor.initial_inference(obs).batch_policy_logits
+    want = trainer.initial_inference(obs).batch_policy_logits
+    assert torch.equal(after, want) and not torch.equal(after, before)
+    assert not actor.load_latest(models)                                # already current
+    other = cartpole.make_config().network_config.network_class
+    from muzero_amd.games import tictactoe
+    ttt = tictactoe.make_config().network_config.network_class(tictactoe.make_config(), seed=0)
+    with pytest.raises(Exception):
+        ttt.load_latest(models)
