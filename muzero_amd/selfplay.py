@@ -227,6 +227,12 @@ class BatchedHistory:
             games.append(h)
         return games
 
+    def save_games(self, filepath: str) -> None:
+        """Writes the games as the reference's serialised GameHistoryList (game_services.py:36-42), the file its
+        ReplayBuffer.load_games reads (interchange.py)."""
+        from . import interchange
+        interchange.save_games(self.to_game_histories(), filepath)
+
     def all_gather(self, group=None):
         """Every rank's finished games, concatenated along the game axis in rank order (RCCL over xGMI on GPUs,
         gloo in the CPU tests).  All ranks must hold the same M and G."""
