@@ -139,12 +139,13 @@ class HipEvents:
 
 
 class MoveEvents:
-    """4 HIP events per simulation, recorded by mz_search_move on the launch stream: before the inference, between its
-    two launches (TicTacToe: job kernel | head kernel), after it, after the tree step.  One set per timed step."""
+    """HIP events per simulation, recorded by mz_search_move on the launch stream: [0] before the inference, [1] after
+    its dominant kernel (TicTacToe: the job kernel; CartPole: the whole inference), [2] after the tree step (TicTacToe:
+    head + tree step are one launch).  One set per sampled timed step."""
 
-    def __init__(self, num_simulations, two_launches):
+    def __init__(self, num_simulations):
         import ctypes
-        self.ev, self.N, self.two, self.ct = HipEvents(), num_simulations, two_launches, ctypes
+        self.ev, self.N, self.ct = HipEvents(), num_simulations, ctypes
         self.sets = []
 
     def new_set(self):
@@ -155,19 +156,15 @@ class MoveEvents:
         return arr
 
     def durations(self):
-        """-> (first kernel s, second kernel s, tree step s), each averaged over the timed region"""
-        first, second, tree = [], [], []
+        """-> (dominant kernel s, rest of the simulation s), each averaged over the sampled steps"""
+        first, rest = [], []
         for arr in self.sets:
             for s in range(self.N):
-                e0, em, e1, e2 = (self.ct.c_void_p(arr[4 * s + j]) for j in range(4))
-                if self.two:
-                    first.append(self.ev.elapsed_ms(e0, em))
-                    second.append(self.ev.elapsed_ms(em, e1))
-                else:
-                    first.append(self.ev.elapsed_ms(e0, e1))
-                tree.append(self.ev.elapsed_ms(e1, e2))
+                e0, em, e1 = (self.ct.c_void_p(arr[4 * s + j]) for j in range(3))
+                first.append(self.ev.elapsed_ms(e0, em))
+                rest.append(self.ev.elapsed_ms(em, e1))
         mean = lambda v: float(np.mean(v)) * 1e-3 if v else None
-        return mean(first), mean(second), mean(tree)
+        return mean(first), mean(rest)
 
 
 class NetworkMove:
@@ -210,7 +207,7 @@ class NetworkMove:
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
-        self.hooks = MoveEvents(wl['N'], two_launches=(wl['net'] == 'tictactoe'))
+        self.hooks = MoveEvents(wl['N'])
         self.gather = TrajectoryGather(T, A, device) if world > 1 else None
 
     def run(self, timed_events=False):
@@ -339,14 +336,14 @@ def main():
     tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
     if with_net:
-        k1, k2, tree_s = move.hooks.durations()
+        k1, rest = move.hooks.durations()
         flops_launch = move.trees_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
         roofline = {'bound': 'mfma', 'kernel': move.dominant, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch}
-        extra = {'second_inference_kernel_us': None if k2 is None else k2 * 1e6, 'tree_step_kernel_us': tree_s * 1e6,
-                 'tree_step_GBps': tree_bytes_launch / tree_s / 1e9, 'mean_path_len': mean_d,
+        rest_name = 'head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else 'tree_step_kernel_us'
+        extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         network = f"{wl['net']} network, random-init weights, fp32 MFMA"
     else:

@@ -192,6 +192,15 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                        int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
                        float* out_value, float* out_logits, float* out_value_raw);
 
+/* mz_infer_recurrent over all T trees of `pool` immediately followed by the tree update with its outputs:
+ * mz_step_logits (with_select != 0: results land in parent_block / action, which are read first as this
+ * simulation's leaf parents and actions) or mz_expand_backprop_logits (with_select == 0, the last simulation).
+ * Same results as the separate calls; for the TicTacToe network the head of the inference and the tree step run as
+ * one launch (each workgroup owns 16 games end to end).  net and pool must use the same device and stream. */
+int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,
+                            int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,
+                            float* out_reward, float* out_value, float* out_logits);
+
 /* ---- one move of T games, enqueued natively (batched MCTSAgent.make_move, reference agent.py:219-232) ------- */
 
 typedef struct mz_move_io {
@@ -218,13 +227,14 @@ typedef struct mz_move_io {
     double* out_minmax;            /* [T, 2] f64 or NULL */
     float* out_policy;             /* [T, A] f32 or NULL */
     int32_t* out_action;           /* [T] i32 or NULL */
-    void** events;                 /* NULL, or HOST array of 4*N hipEvent_t recorded per simulation: before the
-                                      inference, between its two launches (if it has two), after it, after the
-                                      tree step (measurement only) */
+    void** events;                 /* NULL, or HOST array of 4*N hipEvent_t recorded per simulation: [0] before the
+                                      inference, [1] between its two launches (if it has two), [2] and [3] after the
+                                      tree step -- which shares the second launch for the TicTacToe network, so
+                                      [1]..[2] spans head + tree step there (measurement only) */
 } mz_move_io_t;
 
 /* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in
- * the loop, root statistics and action sampling -- about 3N+6 launches on the stream, no host synchronisation. */
+ * the loop, root statistics and action sampling -- about 2N+6 (TicTacToe) or 3N+6 launches on the stream, no host synchronisation. */
 int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
 
 /* ---- batched environments on the device (the callers either side of a move) --------------- *

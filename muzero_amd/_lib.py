@@ -69,6 +69,8 @@ PROTOTYPES = {
     'mz_net_training_steps': (c_int64, [c_void_p]),
     'mz_net_set_mid_event': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_infer_recurrent_step': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_search_move': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(MoveIO)]),
     'mz_infer_recurrent': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),

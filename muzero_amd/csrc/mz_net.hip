@@ -24,6 +24,7 @@
 // CartPole (hidden = 128): one kernel per call, a chain of gemm64 (binary action plane -> bias vector),
 //   softmax over the 101-bin value support and support_to_scalar fused in the epilogue.
 #include "mz_common.h"
+#include "mz_pool_internal.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +143,8 @@ struct TttDev {
     const float* pred_value_w;  // [128]
     const float* pred_policy_w; // [9][128]
     const float* pred_policy_b; // [9]
+    const float* pred_head_p;   // packed [16][128][8]: column 0 = value head, 1..9 = policy heads, others zero
+    const float* pred_head_b;   // [16]: value bias, 9 policy biases, zeros
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     float dyn_reward_b, pred_value_b;
@@ -741,37 +744,47 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
     }
 }
 
-// Kernel B.  grid = ceil(B / (32*MT)).  parent_block only tells which rows are skipped.
-template <bool INITIAL, int MT, int NP>
-__global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, const int* __restrict__ parent_block,
-                                                            const float* __restrict__ ppart, const float* __restrict__ rpart,
-                                                            float* __restrict__ out_reward, float* __restrict__ out_value,
-                                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
-    constexpr int ROWS = 32 * MT;
-    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sW[10 * 128];       // value row + 9 policy rows
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Prediction head of 16 games by one 256-thread workgroup: relu(sum of the NP partial products + bias)
+// (games/tictactoe.py:201) -> Dense 128 -> 128 relu (:204) -> value (tanh, :206) and the 9 policy logits (:208), and
+// the reward head's tanh over the 9 per-cell partial dots (:193-195).  16-row tiles on v_mfma_f32_16x16x4_f32: wave v
+// owns output columns 32v..32v+31 as two 16-column blocks (two independent accumulator chains); the MFMA's four k's
+// per step are k = 8*kb + 2*(lane/16) + h, h = 0,1, so a lane's operands for a kb are one 8-byte load each (packed
+// weights [kb][n][8], activations row-major in LDS).  The ten head outputs are one more 16-column block (wave 0).
+// Results: sOut[game][0..8] logits, [9] value, [10] reward.  Ends with a barrier.
+template <int NP, bool REWARD>
+__device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, const float* __restrict__ ppart,
+                                           const float* __restrict__ rpart, float* sX, float* sH, float (*sOut)[12]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
-    float* sX = sBuf[0];
-    float* sH = sBuf[1];
-    BFrag bw;
-    load_b(bw, w.pred_dense_p, lane, wave);
-    for (int i = tid; i < 1280; i += kThreads) sW[i] = i < 128 ? w.pred_value_w[i] : w.pred_policy_w[i - 128];
-    {   // relu(sum of the NP partial products + bias) (games/tictactoe.py:201): NP = 9 per-cell partials (initial
-        // inference) or 4 per-job ones (recurrent); every load of the tile is issued before the first use
+    const int n16 = lane & 15, q = lane >> 4;
+    float2 bF[2][16], hF[16];
+    {
+        const float2* wp = reinterpret_cast<const float2*>(w.pred_dense_p) + (size_t)(wave * 32 + n16) * 4 + q;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            bF[0][kb] = wp[kb * 512];
+            bF[1][kb] = wp[kb * 512 + 64];
+        }
+    }
+    {   // every load of the tile is issued before the first use
         const int c4 = tid & 31;
         const float4 bn = *reinterpret_cast<const float4*>(w.pred_conv_b + 4 * c4);
-        constexpr int RPT = ROWS / 8;                  // rows per thread
-        float4 v[RPT][NP];
+        float4 v[2][NP];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int b = min(row0 + (tid >> 5) + 8 * i, B - 1);
-            const float4* p = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
+            const float4* pp = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
 #pragma unroll
-            for (int c = 0; c < NP; ++c) v[i][c] = p[c * 32];
+            for (int c = 0; c < NP; ++c) v[i][c] = pp[c * 32];
+        }
+        if (wave == 0) {
+            const float2* hp = reinterpret_cast<const float2*>(w.pred_head_p) + (size_t)n16 * 4 + q;
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) hF[kb] = hp[kb * 512];
         }
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
+        for (int i = 0; i < 2; ++i) {
             float4 s = bn;
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
@@ -785,46 +798,114 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
         }
     }
     __syncthreads();
-    f32x16 acc[MT];
-    zero_acc(acc);
-    mma_tile<MT>(sX, bw, acc, lane);                                    // Dense 128 -> 128 relu (:204)
-    store_acc_lds<MT, true>(acc, w.pred_dense_b, sH, lane, wave);
+    {
+        float2 aF[16];
+        const float* ap = sX + n16 * kLd + 2 * q;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) aF[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, bF[0][kb].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, bF[1][kb].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[0][kb].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[1][kb].y, acc1, 0, 0, 0);
+        }
+        const int n0 = wave * 32 + n16;
+        const float b0 = w.pred_dense_b[n0], b1 = w.pred_dense_b[n0 + 16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {            // C/D layout 16x16: row = 4*(lane/16) + i, col = lane%16
+            sH[(4 * q + i) * kLd + n0] = fmaxf(acc0[i] + b0, 0.f);
+            sH[(4 * q + i) * kLd + n0 + 16] = fmaxf(acc1[i] + b1, 0.f);
+        }
+    }
     __syncthreads();
-    if (tid < ROWS * 4) {
-        const int row = tid >> 2, q = tid & 3, b = row0 + row;
-        const bool live = b < B && (INITIAL || !parent_block || parent_block[b] >= 0);
-        const float* h = sH + row * kLd + q * 32;
-        // value head (tanh, :206) and the 9 policy logits (:208): 10 dots sharing the row's activations
-        float s[10];
+    if (wave == 0) {
+        float2 aF[16];
+        const float* ap = sH + n16 * kLd + 2 * q;
 #pragma unroll
-        for (int o = 0; o < 10; ++o) s[o] = 0.f;
+        for (int kb = 0; kb < 16; ++kb) aF[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // even / odd kb: two chains, added at the end
 #pragma unroll
-        for (int j = 0; j < 32; j += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(h + j);
+        for (int kb = 0; kb < 16; kb += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, hF[kb].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb + 1].x, hF[kb + 1].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, hF[kb].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb + 1].y, hF[kb + 1].y, acc1, 0, 0, 0);
+        }
+        if (n16 < 10) {
+            const float hb = w.pred_head_b[n16];
 #pragma unroll
-            for (int o = 0; o < 10; ++o) {
-                const float4 wv = *reinterpret_cast<const float4*>(sW + o * 128 + q * 32 + j);
-                s[o] += a.x * wv.x + a.y * wv.y + a.z * wv.z + a.w * wv.w;
+            for (int i = 0; i < 4; ++i) {
+                const float v = acc0[i] + acc1[i] + hb;
+                if (n16 == 0) sOut[4 * q + i][9] = tanhf(v);        // value; to_scalar is the identity (config.py:28)
+                else sOut[4 * q + i][n16 - 1] = v;
             }
         }
+    } else if (REWARD && wave == 1 && lane < 16) {
+        const int b = min(row0 + lane, B - 1);
+        float rs = 0.f;
 #pragma unroll
-        for (int o = 0; o < 10; ++o) {
-            s[o] += __shfl_xor(s[o], 1, 4);
-            s[o] += __shfl_xor(s[o], 2, 4);
+        for (int c = 0; c < 9; ++c) rs += rpart[(size_t)b * 9 + c];
+        sOut[lane][10] = tanhf(rs + w.dyn_reward_b);
+    }
+    __syncthreads();
+}
+
+// Kernel B.  grid = ceil(B / 16).  parent_block only tells which rows are skipped.
+template <bool INITIAL, int NP>
+__global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, const int* __restrict__ parent_block,
+                                                            const float* __restrict__ ppart, const float* __restrict__ rpart,
+                                                            float* __restrict__ out_reward, float* __restrict__ out_value,
+                                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw) {
+    __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
+    __shared__ float sOut[16][12];
+    const int row0 = blockIdx.x * 16;
+    ttt_head16<NP, !INITIAL>(w, B, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
+    const int tid = threadIdx.x;
+    if (tid < 16) {
+        const int b = row0 + tid;
+        if (b < B && (INITIAL || !parent_block || parent_block[b] >= 0)) {
+            out_value[b] = sOut[tid][9];
+            if (out_value_raw) out_value_raw[b] = sOut[tid][9];
+#pragma unroll
+            for (int o = 0; o < 9; ++o) out_logits[(size_t)b * 9 + o] = sOut[tid][o];
+            if (!INITIAL) out_reward[b] = sOut[tid][10];
         }
-        if (q == 0 && live) {
-            const float v = tanhf(s[0] + w.pred_value_b);
-            out_value[b] = v;                       // to_scalar is the identity: support_size None (config.py:28)
-            if (out_value_raw) out_value_raw[b] = v;
-#pragma unroll
-            for (int o = 1; o < 10; ++o) out_logits[(size_t)b * 9 + (o - 1)] = s[o] + w.pred_policy_b[o - 1];
-            if (!INITIAL) {
-                float rs = 0.f;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) rs += rpart[(size_t)b * 9 + c];
-                out_reward[b] = tanhf(rs + w.dyn_reward_b);      // reward head, tanh (:194)
-            }
-        }
+    }
+}
+
+// Kernel B fused with the tree step (expand + backprop of this simulation, select of the next: mz_step_logits).
+// One workgroup = 16 games: the head needs nothing but these games' partials and the tree step nothing but their
+// logits / value / reward, which go from the head to the tree code through LDS.  One launch boundary less per
+// simulation.  Tree side: 16 lanes per game (A = 9), exactly step_kernel<16, true>'s code (mz_tree_dev.h), so the trees
+// are bit-identical to the separate launches.
+template <bool SELECT>
+__global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolDev p, int nb, const float* __restrict__ ppart,
+                                                                 const float* __restrict__ rpart, float* __restrict__ out_reward,
+                                                                 float* __restrict__ out_value, float* __restrict__ out_logits,
+                                                                 int* out_parent, int* out_action) {
+    constexpr int G = 16;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
+    __shared__ float sOut[16][12];
+    const int tid = threadIdx.x, row0 = blockIdx.x * 16;
+    ttt_head16<4, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
+    const int tree = row0 + tid / G, gl = tid % G;
+    const bool active = tree < p.T && p.n_root[tree] > 0;
+    if (active && gl < 11) {                                         // the plain outputs of mz_infer_recurrent
+        const float x = sOut[tid / G][gl];
+        if (gl < 9) out_logits[(size_t)tree * 9 + gl] = x;
+        else if (gl == 9) out_value[tree] = x;
+        else out_reward[tree] = x;
+    }
+    // ---- tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
+    const float* mine = sOut[tid / G];
+    backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9]);
+    if (SELECT) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        select_tree<G>(p, tree, active, gl, out_parent, out_action);
     }
 }
 
@@ -1182,6 +1263,13 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             for (int o = 0; o < 9; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 9 + o];
         off.push_back(pk.add(polT));                                   // 14
         off.push_back(pk.add(pred_policy_b, 9));                       // 15
+        std::vector<float> headW(128 * 16, 0.f), headB(16, 0.f);      // [k][16]: value | 9 policy | zeros
+        for (int k = 0; k < 128; ++k) {
+            headW[(size_t)k * 16] = pred_value[k];
+            for (int o = 0; o < 9; ++o) headW[(size_t)k * 16 + 1 + o] = pred_policy[(size_t)k * 9 + o];
+        }
+        headB[0] = pred_value_b[0];
+        for (int o = 0; o < 9; ++o) headB[1 + o] = pred_policy_b[o];
         net->ttt.dyn_reward_b = dyn_reward_b[0];
         net->ttt.pred_value_b = pred_value_b[0];
         // stage descriptors of the four uniform-cost jobs: (kind | 8*first tap | 16*last tap, cell, tap, source cell)
@@ -1215,6 +1303,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         }
         net->ttt.job_first[4] = (int)desc.size() / 4;
         off.push_back(pk.add(desc));                                   // 16
+        off.push_back(pk.add_packed(headW.data(), 128, 16, 16));       // 17
+        off.push_back(pk.add(headB));                                  // 18
     } else {
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
@@ -1297,6 +1387,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         t.pred_policy_w = d + off[14];
         t.pred_policy_b = d + off[15];
         t.job_desc = reinterpret_cast<const int4*>(d + off[16]);
+        t.pred_head_p = d + off[17];
+        t.pred_head_b = d + off[18];
     } else {
         CartDev& c = net->cart;
         c.rep_conv = d + off[0];
@@ -1395,9 +1487,9 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
             ttt_cell_kernel<true, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
                                                                   out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-        const int nhb = (batch + 31) / 32;
-        ttt_head_kernel<true, 1, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                             out_value, out_logits, out_value_raw);
+        const int nhb = (batch + 15) / 16;
+        ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                          out_value, out_logits, out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<true, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
@@ -1445,13 +1537,13 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                                                                    out_hidden, net->ppart, net->rpart, cell_order(),
                                                                    net->trace);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-        const int nhb = (batch + 31) / 32;
+        const int nhb = (batch + 15) / 16;
         if (per_cell)
-            ttt_head_kernel<false, 1, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                                  out_reward, out_value, out_logits, out_value_raw);
+            ttt_head_kernel<false, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                               out_reward, out_value, out_logits, out_value_raw);
         else
-            ttt_head_kernel<false, 1, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                                  out_reward, out_value, out_logits, out_value_raw);
+            ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                               out_reward, out_value, out_logits, out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<false, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs, action,
@@ -1461,6 +1553,50 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                                                                out_hidden, out_reward, out_value, out_logits, out_value_raw);
     }
     return launch_status("recurrent inference");
+}
+
+int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,
+                            int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,
+                            float* out_reward, float* out_value, float* out_logits) {
+    MZ_REQUIRE(net != nullptr && pool != nullptr, "net/pool is NULL");
+    MZ_REQUIRE(hidden_base && parent_block && action && out_hidden && out_reward && out_value && out_logits,
+               "hidden_base/parent_block/action/out_hidden/out_reward/out_value/out_logits is NULL");
+    MZ_REQUIRE(block_stride >= 0, "block_stride must be >= 0");
+    MZ_REQUIRE(net->device == pool->device && net->stream == pool->stream, "net and pool must share device and stream");
+    const int batch = pool->dev.T;
+    static const bool no_fusion = getenv("MZ_NO_FUSED_STEP") != nullptr;          // experiments
+    const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9 && !net->trace && !no_fusion;
+    if (!fusable) {                                   // the same work as separate launches
+        int s = mz_infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward,
+                                   out_value, out_logits, nullptr);
+        if (s != MZ_OK) return s;
+        if (net->mid_event && net->kind != MZ_NET_TICTACTOE) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
+        return with_select ? mz_step_logits(pool, out_logits, out_reward, out_value, parent_block, action)
+                           : mz_expand_backprop_logits(pool, out_logits, out_reward, out_value);
+    }
+    int nb = 0;
+    int s = mz_pool_begin_backprop(pool, with_select != 0, &nb);
+    if (s != MZ_OK) return s;
+    MZ_HIP(hipSetDevice(net->device));
+    s = ensure_scratch(net, batch);
+    if (s != MZ_OK) return s;
+    hipStream_t st = net->stream;
+    const int nrb32 = (batch + 31) / 32;
+    ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                (long)block_stride, action, out_hidden, net->ppart,
+                                                                net->rpart, nullptr);
+    if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+    const int grid = (batch + 15) / 16;
+    if (with_select)
+        ttt_head_step_kernel<true><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart, out_reward,
+                                                              out_value, out_logits, parent_block, action);
+    else
+        ttt_head_step_kernel<false><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart, out_reward,
+                                                               out_value, out_logits, parent_block, action);
+    s = launch_status("recurrent inference + tree step");
+    if (s != MZ_OK) return s;
+    mz_pool_commit_backprop(pool, with_select != 0);
+    return MZ_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,22 @@
+// Host-side state of a tree pool, shared by mz_tree.hip and the fused inference + tree-step launch in mz_net.hip.
+#pragma once
+#include "mz_tree_dev.h"
+#include <vector>
+
+struct mz_pool {
+    PoolDev dev{};
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int G = 2;
+    int blocks_in_use = 0;     // 0 = roots not expanded; else simulations done + 1
+    bool pending = false;      // a select is waiting for its expand_backprop
+    long long select_launches = 0, backprop_launches = 0;
+    size_t bytes = 0;
+    std::vector<void*> allocations;
+    long long* counter_scratch = nullptr;
+};
+
+// Call-sequence bookkeeping of one expand+backprop (fused with the next select when `with_select`): checks what
+// mz_step / mz_expand_backprop check and returns the block the new nodes take; commit after a successful launch.
+int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block);
+void mz_pool_commit_backprop(mz_pool* pool, bool with_select);

@@ -1,7 +1,7 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as ~3N+6 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as ~2N+6 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 
@@ -29,13 +29,9 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
             MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s]), static_cast<hipStream_t>(io->stream)));
             MZ_TRY_(mz_net_set_mid_event(net, ev[4 * s + 1]));
         }
-        MZ_TRY_(mz_infer_recurrent(net, T, io->hidden, io->parent_block, (int64_t)T * H, io->action,
-                                   io->hidden + (size_t)(s + 1) * T * H, io->reward, io->value, io->logits, nullptr));
+        MZ_TRY_(mz_infer_recurrent_step(net, pool, s + 1 < N, io->hidden, io->parent_block, (int64_t)T * H, io->action,
+                                        io->hidden + (size_t)(s + 1) * T * H, io->reward, io->value, io->logits));
         if (ev) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
-        if (s + 1 < N)
-            MZ_TRY_(mz_step_logits(pool, io->logits, io->reward, io->value, io->parent_block, io->action));
-        else
-            MZ_TRY_(mz_expand_backprop_logits(pool, io->logits, io->reward, io->value));
         if (ev) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 3]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
