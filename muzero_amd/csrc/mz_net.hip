@@ -889,9 +889,10 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
     const int tid = threadIdx.x, row0 = blockIdx.x * 16;
-    ttt_head16<4, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
     const int tree = row0 + tid / G, gl = tid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
+    const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
+    ttt_head16<4, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
     if (active && gl < 11) {                                         // the plain outputs of mz_infer_recurrent
         const float x = sOut[tid / G][gl];
         if (gl < 9) out_logits[(size_t)tree * 9 + gl] = x;
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     }
     // ---- tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
     const float* mine = sOut[tid / G];
-    backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9]);
+    backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9], pf);
     if (SELECT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();

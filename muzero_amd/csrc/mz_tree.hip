@@ -52,8 +52,9 @@ __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int 
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
+    const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
     backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f);
+                             active ? value[tree] : 0.f, pf);
 }
 
 // expand+backprop of simulation s fused with select of simulation s+1: the group re-reads records it has
@@ -65,8 +66,9 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(PoolDev p, int nb, 
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
+    const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
     backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f);
+                             active ? value[tree] : 0.f, pf);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -457,6 +459,8 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         MZ_CREATE_HIP(hipMemset(d.sims, 0, (size_t)d.T * sizeof(long long)));
         MZ_CREATE_HIP(hipMemset(d.err_flag, 0, sizeof(int)));
         MZ_CREATE_HIP(hipMemset(d.path_len, 0, (size_t)d.T * sizeof(int)));
+        // zeroed: the backup prefetches path slots before it knows the path length (mz_tree_dev.h, BackupPrefetch)
+        MZ_CREATE_HIP(hipMemset(d.path, 0, (size_t)d.T * (d.N + 1) * sizeof(int)));
 #undef MZ_CREATE_HIP
         d.log_table = log_dev;
         d.sum_leaf = leaf_dev;
