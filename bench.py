@@ -223,6 +223,22 @@ class NetworkMove:
             self.gather.wait()
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic_<workload>.json:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be
+    read from inside this process, so the figure is the one of the latest committed profile; None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*_hbm_traffic_{workload}.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for name, row in data.get('kernels', {}).items():
+        if name.startswith(kernel):
+            return row['traffic_bytes_per_launch'], os.path.basename(files[-1])
+    return None, None
+
+
 def cpu_baseline(wl, seconds):
     """The CPU oracle -- a port of the reference's Python MCTS (oracle/mcts_oracle.py) calling the numpy network
     port (oracle/net_oracle.py, float32, batch 1 per simulation like agent.py:204-207) -- on ONE host core, same
@@ -339,8 +355,11 @@ def main():
         k1, rest = move.hooks.durations()
         flops_launch = move.trees_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
+        traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
+                                else (None, None))
         roofline = {'bound': 'mfma', 'kernel': move.dominant, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch}
         rest_name = 'head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else 'tree_step_kernel_us'
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
