@@ -7,7 +7,8 @@ struct mz_pool {
     PoolDev dev{};
     hipStream_t stream = nullptr;
     int device = 0;
-    int G = 2;
+    int G = 2;                 // lanes per tree
+    int P = 1;                 // children per lane loaded together by the descending kernels
     int blocks_in_use = 0;     // 0 = roots not expanded; else simulations done + 1
     bool pending = false;      // a select is waiting for its expand_backprop
     long long select_launches = 0, backprop_launches = 0;

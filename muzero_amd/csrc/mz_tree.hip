@@ -10,12 +10,17 @@
 //   run_mcts loop body         agent.py:198-211
 //   select_action/softmax      agent.py:162-168,213-217
 //
-// Layout.  Tree t owns N+1 records ("blocks") of RS bytes, block e at blocks + (t*(N+1)+e)*RS:
-//     value_sum f64[A] | visit_count i32[A] | prior f32[A] | reward f32[A] | child i32[A]      (24*A, padded to 64 B)
-// so one dependent step of a descent reads ONE contiguous record (A=9: two 128-B lines) and the lanes of a
-// group read each field coalesced.  Block e is the node expanded by simulation e-1 in every tree (lockstep),
-// block 0 is the root.  Only visit_count and prior are initialised at expansion; value_sum/reward/child of a
-// slot are written by the first backup through it (visited <=> expanded) and never read before.
+// Layout.  Tree t owns N+1 records ("blocks") of RS bytes (a multiple of 128), block e at blocks + (t*(N+1)+e)*RS:
+//     select half:  q f64[A] | visit_count i32[A] | prior f32[A] | child i32[A]          (20*A bytes, SoA)
+//     backup half:  { value_sum f64, reward f32, pad } [A]                               (16*A bytes, AoS)
+// One dependent step of a descent reads the contiguous select half with every field coalesced over the lanes of a
+// group; a backup touches ONE 16-byte backup entry per path node (its visit count travels in the path entry) and
+// writes count and q of that slot.  q = reward + discount*value_sum/visit_count, the exploitation term of ucb_score
+// (agent.py:188), already normalised when the value bounds are known: computed once per backup with the same IEEE
+// operations the reference performs at every look, so select divides only for visited children.
+// Block e is the node expanded by simulation e-1 in every tree (lockstep), block 0 is the root.  Only visit_count
+// and prior are initialised at expansion; q/child/value_sum/reward of a slot are written by the first backup
+// through it (visited <=> expanded) and never read before.
 // Root priors are fp64 after the noise mix (agent.py:175) and live in root_prior[T][A] with the root's
 // action list root_action[T][A].
 //
@@ -38,13 +43,21 @@
 
 namespace {
 
-template <int G>
-__global__ __launch_bounds__(kBlockThreads) void select_kernel(PoolDev p, int* out_parent, int* out_action) {
+// one child per lane: all 8 wavefronts per SIMD resident (64 VGPRs), so a 16384-tree launch needs one round of workgroups
+#define MZ_WAVES(P) __attribute__((amdgpu_waves_per_eu((P) == 1 ? 8 : 1, 8)))
+
+template <int G, int P>
+__global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolDev p, int* out_parent, int* out_action) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
-    select_tree<G>(p, tree, active, gl, out_parent, out_action);
+    select_tree<G, P>(p, tree, active, gl, out_parent, out_action);
 }
+
+// LDS row of one wavefront for the softmax terms of a wide action axis (one tree per wavefront: G == 64)
+#define MZ_SUM_LDS(G, LOGITS)                                                                      \
+    __shared__ float s_sum[(G == 64 && LOGITS) ? kBlockThreads / 64 : 1][(G == 64 && LOGITS) ? kSumLdsRow : 1]; \
+    float* lds_row = (G == 64 && LOGITS) ? s_sum[threadIdx.x / 64] : nullptr
 
 template <int G, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int nb, const float* pol,
@@ -52,27 +65,29 @@ __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int 
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
+    MZ_SUM_LDS(G, LOGITS);
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
     backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f, pf);
+                             active ? value[tree] : 0.f, pf, lds_row);
 }
 
-// expand+backprop of simulation s fused with select of simulation s+1: the group re-reads records it has
-// just written, so the writes are released/acquired at workgroup scope (same CU, same L1).
-template <int G, bool LOGITS>
-__global__ __launch_bounds__(kBlockThreads) void step_kernel(PoolDev p, int nb, const float* pol,
+// expand+backprop of simulation s fused with select of simulation s+1.  A tree's group lies inside one wavefront, whose
+// vector memory operations are performed in program order, so the records it has just written are the ones it reads
+// back: a wavefront-scope fence (compiler ordering only) is enough, and the wavefronts of a workgroup stay decoupled.
+template <int G, int P, bool LOGITS>
+__global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev p, int nb, const float* pol,
                                                              const float* reward, const float* value,
                                                              int* out_parent, int* out_action) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
+    MZ_SUM_LDS(G, LOGITS);
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
     backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f, pf);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    select_tree<G>(p, tree, active, gl, out_parent, out_action);
+                             active ? value[tree] : 0.f, pf, lds_row);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    select_tree<G, P>(p, tree, active, gl, out_parent, out_action);
 }
 
 // Root expansion (agent.py:154-160 on the root; positional priors, trap T5).
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        total = numpy_sum_f32<G>(p, f_prior(p, r), f_reward(p, r), (in && n > 0) ? gl : 1 << 30);
+        total = numpy_sum_f32<G>(p, f_prior(p, r), reinterpret_cast<float*>(f_child(p, r)), (in && n > 0) ? gl : 1 << 30);
     }
     if (!in) return;
     int* cnt = f_count(p, r);
@@ -305,6 +320,29 @@ void dispatch_group(int G, F&& f) {
     }
 }
 
+// (G, P) for the kernels that descend: P children per lane are loaded together (1 unless the action axis is wider
+// than a wavefront, then the power of two covering ceil(A / 64), at most 8)
+template <typename F>
+void dispatch_group_passes(int G, int P, F&& f) {
+    if (G < 64 || P <= 1) {
+        dispatch_group(G, [&](auto g) { f(g, std::integral_constant<int, 1>{}); });
+        return;
+    }
+    std::integral_constant<int, 64> g;
+    switch (P) {
+        case 2: f(g, std::integral_constant<int, 2>{}); break;
+        case 4: f(g, std::integral_constant<int, 4>{}); break;
+        default: f(g, std::integral_constant<int, 8>{}); break;
+    }
+}
+
+int passes_for(int A, int G) {
+    const int need = (A + G - 1) / G;
+    int P = 1;
+    while (P < need && P < 8) P <<= 1;
+    return P;
+}
+
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -338,13 +376,14 @@ int backprop_impl(mz_pool* pool, const float* pol, const float* reward, const fl
     MZ_TRY(mz_pool_begin_backprop(pool, fused, &nb));
     MZ_HIP(hipSetDevice(pool->device));
     const int grid = grid_for(pool);
-    dispatch_group(pool->G, [&](auto g) {
+    dispatch_group_passes(pool->G, pool->P, [&](auto g, auto pp) {
         constexpr int G = decltype(g)::value;
+        constexpr int P = decltype(pp)::value;
         hipStream_t st = pool->stream;
         if (fused && logits)
-            step_kernel<G, true><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
+            step_kernel<G, P, true><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
         else if (fused)
-            step_kernel<G, false><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
+            step_kernel<G, P, false><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value, out_parent, out_action);
         else if (logits)
             backprop_kernel<G, true><<<grid, kBlockThreads, 0, st>>>(pool->dev, nb, pol, reward, value);
         else
@@ -409,13 +448,15 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         d.A = cfg->num_actions;
         d.N = cfg->max_simulations;
         d.has_bounds = cfg->has_known_bounds ? 1 : 0;
-        d.RS = (24 * d.A + 63) / 64 * 64;
+        d.off_back = (20 * d.A + 15) / 16 * 16;
+        d.RS = (d.off_back + 16 * d.A + 127) / 128 * 128;
         d.tree_stride = (size_t)(d.N + 1) * (size_t)d.RS;
         d.discount = cfg->num_players == 2 ? -cfg->discount : cfg->discount;      // agent.py:150-152
         d.default_value = cfg->default_value;
         d.kmin = cfg->known_min;
         d.kmax = cfg->known_max;
         pool->G = group_width(d.A);
+        pool->P = passes_for(d.A, pool->G);
         const size_t TA = (size_t)d.T * d.A;
         double* log_dev = nullptr;
         int* leaf_dev = nullptr;
@@ -460,7 +501,7 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         MZ_CREATE_HIP(hipMemset(d.err_flag, 0, sizeof(int)));
         MZ_CREATE_HIP(hipMemset(d.path_len, 0, (size_t)d.T * sizeof(int)));
         // zeroed: the backup prefetches path slots before it knows the path length (mz_tree_dev.h, BackupPrefetch)
-        MZ_CREATE_HIP(hipMemset(d.path, 0, (size_t)d.T * (d.N + 1) * sizeof(int)));
+        MZ_CREATE_HIP(hipMemset(d.path, 0, (size_t)d.T * (d.N + 1) * sizeof(int2)));
 #undef MZ_CREATE_HIP
         d.log_table = log_dev;
         d.sum_leaf = leaf_dev;
@@ -524,9 +565,10 @@ int mz_select(mz_pool_t* pool, int32_t* out_parent_block, int32_t* out_action) {
         return mz::fail(MZ_ERR_STATE, "pool is full: %d simulations done", pool->blocks_in_use - 1);
     MZ_HIP(hipSetDevice(pool->device));
     const int grid = grid_for(pool);
-    dispatch_group(pool->G, [&](auto g) {
+    dispatch_group_passes(pool->G, pool->P, [&](auto g, auto pp) {
         constexpr int G = decltype(g)::value;
-        select_kernel<G><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, out_parent_block, out_action);
+        constexpr int P = decltype(pp)::value;
+        select_kernel<G, P><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, out_parent_block, out_action);
     });
     MZ_TRY(check_launch("select_kernel"));
     pool->select_launches++;
@@ -605,11 +647,10 @@ int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* ou
     std::vector<char> recbuf(d.RS);
     MZ_HIP(hipMemcpy(recbuf.data(), d.blocks + (size_t)tree * d.tree_stride + (size_t)block * d.RS, d.RS,
                      hipMemcpyDeviceToHost));
-    const double* vs = reinterpret_cast<const double*>(recbuf.data());
     const int* cnt = reinterpret_cast<const int*>(recbuf.data() + 8 * (size_t)A);
     const float* pr = reinterpret_cast<const float*>(recbuf.data() + 12 * (size_t)A);
-    const float* rw = reinterpret_cast<const float*>(recbuf.data() + 16 * (size_t)A);
-    const int* ch = reinterpret_cast<const int*>(recbuf.data() + 20 * (size_t)A);
+    const int* ch = reinterpret_cast<const int*>(recbuf.data() + 16 * (size_t)A);
+    const BackSlot* back = reinterpret_cast<const BackSlot*>(recbuf.data() + d.off_back);
     std::vector<double> rprior(A);
     std::vector<int> ract(A);
     if (block == 0) {
@@ -620,9 +661,9 @@ int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* ou
         const bool visited = cnt[k] > 0;
         if (actions) actions[k] = block == 0 ? ract[k] : k;
         if (count) count[k] = cnt[k];
-        if (value_sum) value_sum[k] = visited ? vs[k] : 0.0;
+        if (value_sum) value_sum[k] = visited ? back[k].vsum : 0.0;
         if (prior) prior[k] = block == 0 ? rprior[k] : (double)pr[k];
-        if (reward) reward[k] = visited ? rw[k] : std::numeric_limits<float>::quiet_NaN();
+        if (reward) reward[k] = visited ? back[k].reward : std::numeric_limits<float>::quiet_NaN();
         if (child) child[k] = visited ? ch[k] : -1;
     }
     return MZ_OK;

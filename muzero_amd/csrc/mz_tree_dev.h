@@ -7,14 +7,24 @@
 namespace {
 
 constexpr int kBlockThreads = 256;
-constexpr int kPathShift = 12;                 // path entry = (block << 12) | child index
+constexpr int kPathShift = 12;                 // path entry .x = (block << 12) | child index
 constexpr int kMaxActions = 1 << kPathShift;   // 4096
-constexpr int kMaxSimulations = (1 << 19) - 2;
+constexpr int kMaxSimulations = (1 << 19) - 2; // (count << 12 | action) and (block << 12 | slot) stay below 2^31
+constexpr int kSumLdsMax = 1024;               // widest action axis whose softmax terms are staged in LDS
+constexpr int kSumLdsRow = kSumLdsMax + 32;    // + the leaf sums of the NumPy pairwise recursion
+
+// Backup half of a child slot (array of structures: one 16-byte access per path node).
+struct __attribute__((aligned(16))) BackSlot {
+    double vsum;      // Node.value_sum (agent.py:112)
+    float reward;     // Node.reward (agent.py:156)
+    int pad;
+};
 
 struct PoolDev {
     int T, A, N;
     int has_bounds;
-    int RS;                    // record stride in bytes
+    int RS;                    // record stride in bytes (multiple of 128)
+    int off_back;              // byte offset of the BackSlot array inside a record
     size_t tree_stride;        // (N+1)*RS
     char* blocks;
     double* root_prior;        // [T][A]
@@ -24,7 +34,7 @@ struct PoolDev {
     double* root_vsum;         // [T]
     double* mm_min;            // [T]
     double* mm_max;            // [T]
-    int* path;                 // [T][N+1]
+    int2* path;                // [T][N+1]: {(block << 12) | slot, the slot's visit count when it was selected}
     int* path_len;             // [T]
     long long* sum_len;        // [T] cumulative sum of path lengths backed up (measurement)
     long long* sims;           // [T] cumulative simulations backed up
@@ -36,21 +46,95 @@ struct PoolDev {
     double discount, default_value, kmin, kmax;
 };
 
+// Record of one expanded node (block e of tree t), A child slots:
+//   select half, structure of arrays:  q f64[A] | visit_count i32[A] | prior f32[A] | child i32[A]      (20*A bytes)
+//   backup half, array of structures:  { value_sum f64, reward f32, pad } [A] at off_back               (16*A bytes)
+// q is what ucb_score needs of a visited child, computed once per backup instead of once per look:
+//   reward + discount*value (agent.py:188), and with known bounds already MinMaxStats.normalize'd (utils.py:68-76).
 __device__ __forceinline__ char* rec(const PoolDev& p, int tree, int e) {
     return p.blocks + (size_t)tree * p.tree_stride + (size_t)e * (size_t)p.RS;
 }
-__device__ __forceinline__ double* f_vsum(const PoolDev& p, char* r) { return reinterpret_cast<double*>(r); }
+__device__ __forceinline__ double* f_q(const PoolDev& p, char* r) { return reinterpret_cast<double*>(r); }
 __device__ __forceinline__ int* f_count(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 8 * (size_t)p.A); }
 __device__ __forceinline__ float* f_prior(const PoolDev& p, char* r) { return reinterpret_cast<float*>(r + 12 * (size_t)p.A); }
-__device__ __forceinline__ float* f_reward(const PoolDev& p, char* r) { return reinterpret_cast<float*>(r + 16 * (size_t)p.A); }
-__device__ __forceinline__ int* f_child(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 20 * (size_t)p.A); }
+__device__ __forceinline__ int* f_child(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 16 * (size_t)p.A); }
+__device__ __forceinline__ BackSlot* f_back(const PoolDev& p, char* r) { return reinterpret_cast<BackSlot*>(r + p.off_back); }
 
 // ---------------------------------------------------------------------------------------------------
-// select_leaf (agent.py:177-190) for one tree by a group of G lanes.  Every lane of the wavefront calls
-// this (inactive lanes with active=false) because the reduction shuffles must be wave-uniform.
+// All-lanes reductions inside groups of G consecutive lanes without touching LDS: butterfly steps 1 and 2 are DPP
+// quad permutes, 4 and 8 the DPP half-row / row mirrors (valid because the operator is commutative and the previous
+// steps made quads / half rows uniform), 16 and 32 the gfx950 row / half-wave swaps.
 // ---------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(dpp_i32<CTRL>(__float_as_int(x)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(x)), dpp_i32<CTRL>(__double2loint(x)));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+__device__ __forceinline__ double max_f64(double a, double b) { return b > a ? b : a; }   // operands are never NaN
+__device__ __forceinline__ double min_f64(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ int max_i32(int a, int b) { return b > a ? b : a; }
+
+template <int G, bool MAX>
+__device__ __forceinline__ double group_minmax_f64(double x) {
+    auto op = [](double a, double b) { return MAX ? max_f64(a, b) : min_f64(a, b); };
+    if (G >= 2) x = op(x, dpp_f64<kDppXor1>(x));
+    if (G >= 4) x = op(x, dpp_f64<kDppXor2>(x));
+    if (G >= 8) x = op(x, dpp_f64<kDppHalfMirror>(x));
+    if (G >= 16) x = op(x, dpp_f64<kDppMirror>(x));
+    if (G >= 32) {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = op(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+    }
+    if (G >= 64) {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = op(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+    }
+    return x;
+}
+
 template <int G>
+__device__ __forceinline__ int group_max_i32(int x) {
+    if (G >= 2) x = max_i32(x, dpp_i32<kDppXor1>(x));
+    if (G >= 4) x = max_i32(x, dpp_i32<kDppXor2>(x));
+    if (G >= 8) x = max_i32(x, dpp_i32<kDppHalfMirror>(x));
+    if (G >= 16) x = max_i32(x, dpp_i32<kDppMirror>(x));
+    if (G >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        x = max_i32((int)r[0], (int)r[1]);
+    }
+    if (G >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        x = max_i32((int)r[0], (int)r[1]);
+    }
+    return x;
+}
+
+// keeps a loaded value in a register at this point of the program: the compiler can neither sink its load into a
+// later conditional block nor wait for it earlier than here
+__device__ __forceinline__ void pin(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+
+// ---------------------------------------------------------------------------------------------------
+// select_leaf (agent.py:177-190) for one tree by a group of G lanes; lane gl scores children gl, gl+G, ...  Every
+// lane of the wavefront calls this (inactive lanes with active=false): the reductions are wave-wide instructions.
+// P = children per lane whose loads are in flight together (P*G >= A for one round trip per level).
+// ---------------------------------------------------------------------------------------------------
+template <int G, int P = 1>
 __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int* out_parent, int* out_action) {
+    const int A = p.A;
     int e = 0, np_ = 0, nchild = 0, depth = 0;
     bool done = !active;
     bool ident = false;            // MinMaxStats.normalize returns the value unchanged (utils.py:71-72)
@@ -65,83 +149,103 @@ __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int
             nd = mx - mn;
         }
     }
+    // isnan(child.value) -> the default value, normalised like any other (agent.py:188, utils.py:68-76): the
+    // exploitation term of every unvisited child
+    const double dflt = ident ? p.default_value : (p.default_value - na) / nd;
+    const bool renorm = !p.has_bounds && !ident;             // q holds raw reward + discount*value
+    const int gbase = (int)(threadIdx.x & 63u) & ~(G - 1);   // first lane of this group in the wavefront
+    const double ninf = -std::numeric_limits<double>::infinity();
     for (int it = 0; it <= p.N; ++it) {          // a path holds at most N+1 nodes: every wave reaches the exit
         if (!__any(!done)) break;
-        double bs = 0.0;
-        int bkey = -1, bc = 0, bchild = 0;        // local best: key, its visit count and child block
-        int s0nan = 0, c0 = 0, child0 = 0, act0 = 0;   // child 0 (lane 0): the winner when its score is NaN
+        const bool root = (it == 0);             // block 0 is only ever the first node of a path
+        double bs = ninf;
+        int bkey = -1, bcc = 0, bch = 0;         // local best: key, (count << 12 | action), child block
+        int s0nan = 0, cc0 = 0, ch0 = 0;         // child 0 (lane 0 of the group): the winner when its score is NaN
         if (!done) {
-            // One dependent round trip per level: every field of every child this lane owns is requested before
-            // anything is computed (value_sum / reward / child of an unvisited slot are garbage and unused), and
-            // the winner's count and child block come back through a shuffle, not through a second load.
             char* r = rec(p, tree, e);
-            const double* vs = f_vsum(p, r);
+            const double* qv = f_q(p, r);
             const int* cnt = f_count(p, r);
-            const float* pr = f_prior(p, r);
-            const float* rw = f_reward(p, r);
+            const float* prf = f_prior(p, r);
             const int* chd = f_child(p, r);
             const double lt = p.log_table[np_];                       // 2*log(Np+1), config.py:159-160
-            const bool root = (e == 0);
-            for (int k = gl; k < nchild; k += G) {
-                const int c = cnt[k];
-                const double vsum = vs[k];
-                const float rwd = rw[k];
-                const int ch = chd[k];
-                const double prior = root ? p.root_prior[(size_t)tree * p.A + k] : (double)pr[k];
-                const int act = root ? p.root_action[(size_t)tree * p.A + k] : k;
-                const double val = vsum / (double)(c > 0 ? c : 1);    // Node.value, agent.py:122
-                const bool visited = c > 0 && val == val;
-                // isnan(node.value) -> default value, agent.py:188
-                const double exploit = visited ? (double)rwd + p.discount * val : p.default_value;
-                const double nrm = ident ? exploit : (exploit - na) / nd;          // utils.py:68-76
-                const double sc = nrm + prior * (lt / (double)(c + 1));            // agent.py:189-190
-                const int key = (act << 16) | k;
-                if (k == 0) {
-                    s0nan = (sc != sc);
-                    c0 = c;
-                    child0 = ch;
-                    act0 = act;
-                }
-                if (sc == sc && (bkey < 0 || sc > bs || (sc == bs && key > bkey))) {
-                    bs = sc;
-                    bkey = key;
-                    bc = c;
-                    bchild = ch;
-                }
-            }
-        }
-        const int lkey = bkey;                    // this lane's own best, kept to recognise the owner of the winner
+            for (int base = 0; base < nchild; base += P * G) {
+                // One dependent round trip per level: every field of every child this lane owns is requested
+                // before anything is computed (q / child of an unvisited slot are garbage and unused), and the
+                // winner's count and child block come back through a shuffle, not through a second load.
+                int c[P], ch[P], act[P];
+                double q[P], pr[P];
 #pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            const double os = __shfl_xor(bs, off, G);
-            const int ok = __shfl_xor(bkey, off, G);
-            if (ok >= 0 && (bkey < 0 || os > bs || (os == bs && ok > bkey))) {
-                bs = os;
-                bkey = ok;
+                for (int j = 0; j < P; ++j) {
+                    const int k = min(base + j * G + gl, nchild - 1);
+                    c[j] = cnt[k];
+                    q[j] = qv[k];
+                    ch[j] = chd[k];
+                    if (root) {
+                        pr[j] = p.root_prior[(size_t)tree * A + k];
+                        act[j] = p.root_action[(size_t)tree * A + k];
+                    } else {
+                        pr[j] = (double)prf[k];
+                        act[j] = k;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    pin(c[j]);
+                    pin(q[j]);
+                    pin(ch[j]);
+                    pin(pr[j]);
+                    pin(act[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int k = base + j * G + gl;
+                    if (k < nchild) {
+                        double x = dflt, ex = lt;                             // unvisited: lt / (0 + 1) == lt
+                        if (c[j] > 0) {
+                            x = renorm ? (q[j] - na) / nd : q[j];             // utils.py:68-76
+                            ex = lt / (double)(c[j] + 1);                     // config.py:160
+                        }
+                        const double sc = x + pr[j] * ex;                     // agent.py:189-190
+                        const int key = (act[j] << 16) | k;
+                        const int cc = (c[j] << kPathShift) | act[j];
+                        if (k == 0) {
+                            s0nan = (sc != sc);
+                            cc0 = cc;
+                            ch0 = ch[j];
+                        }
+                        if (sc == sc && (bkey < 0 || sc > bs || (sc == bs && key > bkey))) {
+                            bs = sc;
+                            bkey = key;
+                            bcc = cc;
+                            bch = ch[j];
+                        }
+                    }
+                }
             }
         }
-        s0nan = __shfl(s0nan, 0, G);
+        // arg-max over the group: the largest non-NaN score, ties to the largest (action, index) key (trap T1)
+        const double gmax = group_minmax_f64<G, true>(bs);
+        const int gkey = group_max_i32<G>((bkey >= 0 && bs == gmax) ? bkey : -1);
         // Python's max() over (score, action, child) tuples never replaces a NaN-scored first element and never
         // accepts a NaN-scored later one (agent.py:184): NaN first child wins, else the non-NaN arg-max.
-        const bool first_wins = s0nan || bkey < 0;
-        const int k = first_wins ? 0 : (bkey & 0xffff);
+        const bool first_wins = ((__ballot(s0nan != 0) >> gbase) & 1ull) != 0 || gkey < 0;
+        const int k = first_wins ? 0 : (gkey & 0xffff);
         const int owner = first_wins ? 0 : (k & (G - 1));            // child k is scored by lane k % G
-        (void)lkey;
-        const int wc = __shfl(first_wins ? c0 : bc, owner, G);
-        const int wchild = __shfl(first_wins ? child0 : bchild, owner, G);
-        const int wact = first_wins ? __shfl(act0, 0, G) : (bkey >> 16);
+        const int wcc = __shfl(first_wins ? cc0 : bcc, owner, G);
+        const int wchild = __shfl(first_wins ? ch0 : bch, owner, G);
+        const int wc = wcc >> kPathShift;
         if (!done) {
-            if (gl == 0) p.path[(size_t)tree * (p.N + 1) + depth] = (e << kPathShift) | k;
+            if (gl == 0) p.path[(size_t)tree * (p.N + 1) + depth] = make_int2((e << kPathShift) | k, wc);
             if (wc > 0) {                    // visited <=> expanded: descend (agent.py:179-180)
                 np_ = wc;
                 e = wchild;
-                nchild = p.A;
+                nchild = A;
                 ++depth;
             } else {
                 done = true;
                 if (gl == 0) {
                     out_parent[tree] = e;
-                    out_action[tree] = wact;
+                    out_action[tree] = wcc & (kMaxActions - 1);
                     p.path_len[tree] = depth + 1;
                 }
             }
@@ -159,9 +263,9 @@ __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int
     }
 }
 
-// NumPy float32 pairwise summation (trap T4) of a[0..A) by the lanes of one group.  The host compiled the
-// recursion for n = A into leaves (lo, n<=128) and merges (dst += src); lanes 0..7 are the eight strided
-// accumulators of a leaf.  `scratch` (>= n_sum_leaf floats) receives the leaf sums.  Returns the sum in
+// NumPy float32 pairwise summation (trap T4) of a[0..A) by the lanes of one group, through global memory.  The
+// host compiled the recursion for n = A into leaves (lo, n<=128) and merges (dst += src); lanes 0..7 are the eight
+// strided accumulators of a leaf.  `scratch` (>= n_sum_leaf floats) receives the leaf sums.  Returns the sum in
 // every lane.  Requires the group to have made a[] visible (workgroup fence + barrier by the caller).
 template <int G>
 __device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch, int gl) {
@@ -204,6 +308,39 @@ __device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch,
     return __shfl(total, 0, G);
 }
 
+// The same summation over a row staged in LDS by ONE wavefront (G == 64): eight lanes per leaf, eight leaves at a
+// time, the 8-accumulator combine by DPP.  a[0..A) and scratch[0..n_sum_leaf) are LDS of this wavefront only, whose
+// DS operations execute in program order, so no barrier is needed.  Returns the sum in every lane.
+__device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int lane) {
+    const int oct = lane >> 3, i = lane & 7;
+    for (int s0 = 0; s0 < p.n_sum_leaf; s0 += 8) {
+        const int s = s0 + oct;
+        const bool has = s < p.n_sum_leaf;
+        const int lo = has ? p.sum_leaf[2 * s] : 0, n = has ? p.sum_leaf[2 * s + 1] : 0;
+        const int nfull = n - (n % 8);
+        float r = 0.f;
+        if (nfull >= 8) {
+            r = a[lo + i];
+            for (int m = 8; m < nfull; m += 8) r += a[lo + m + i];
+        }
+        r += dpp_f32<kDppXor1>(r);                 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): fp32 + is commutative,
+        r += dpp_f32<kDppXor2>(r);                 // so every lane of the octet ends with lane 0's bits
+        r += dpp_f32<kDppHalfMirror>(r);
+        if (has && i == 0) {
+            float res = n < 8 ? 0.f : r;
+            for (int t = nfull; t < n; ++t) res += a[lo + t];
+            scratch[s] = res;
+        }
+    }
+    if (lane == 0) {
+        for (int m = 0; m < p.n_sum_merge; ++m) {
+            const int dst = p.sum_merge[2 * m], src = p.sum_merge[2 * m + 1];
+            scratch[dst] = scratch[dst] + scratch[src];
+        }
+    }
+    return scratch[0];
+}
+
 // NumPy float32 pairwise summation of one value per lane (lane k < n holds a[k], the others 0), n <= G <= 64: the
 // single-leaf case of the recursion above, entirely in registers.  Returns the sum in every lane of the group.
 template <int G>
@@ -212,13 +349,12 @@ __device__ __forceinline__ float numpy_sum_lanes(float x, int n, int gl) {
     if (n < 8) {
         for (int i = 0; i < n; ++i) res += __shfl(x, i, G);
     } else {
-        constexpr int W = G < 8 ? G : 8;
         const int nfull = n - (n % 8);
         float r = x;                                                   // lanes 0..7: the eight strided accumulators
         for (int i = 8; i < nfull; i += 8) r += __shfl(x, (gl + i) & (G - 1), G);
-        r += __shfl_xor(r, 1, W);                                      // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
-        r += __shfl_xor(r, 2, W);
-        r += __shfl_xor(r, 4, W);
+        r += dpp_f32<kDppXor1>(r);                                     // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+        r += dpp_f32<kDppXor2>(r);
+        r += dpp_f32<kDppHalfMirror>(r);
         res = r;
         for (int i = nfull; i < n; ++i) res += __shfl(x, i, G);
     }
@@ -229,9 +365,9 @@ __device__ __forceinline__ float numpy_sum_lanes(float x, int n, int gl) {
 // expand_node(leaf, all actions) + backpropagate(leaf, value)  (agent.py:208-211, 154-160, 192-196)
 // ---------------------------------------------------------------------------------------------------
 // What the backup reads before it can do anything, requested as early as the caller can (the fused inference +
-// tree kernel asks for it before the network head runs): the path length, this lane's path slot (position gl,
-// counted from the root; entries past the length are stale but valid: the path array starts zeroed), the slot's
-// statistics, and the root's.
+// tree kernel asks for it before the network head runs): the path length, this lane's path entry (position gl,
+// counted from the root; entries past the length are stale but valid: the path array starts zeroed) with the slot's
+// visit count as select saw it, the slot's backup half, and the root's statistics.
 struct BackupPrefetch {
     int len, slot, c, root_count;
     double vs, root_vsum;
@@ -250,22 +386,49 @@ __device__ __forceinline__ BackupPrefetch backprop_prefetch(const PoolDev& p, in
     f.rw = 0.f;
     if (active) {
         f.len = p.path_len[tree];
-        f.slot = p.path[(size_t)tree * (p.N + 1) + min(gl, p.N)];
+        const int2 pe = p.path[(size_t)tree * (p.N + 1) + min(gl, p.N)];
+        f.slot = pe.x;
+        f.c = pe.y;
         f.root_count = p.root_count[tree];
         f.root_vsum = p.root_vsum[tree];
-        const int k = f.slot & (kMaxActions - 1);
-        char* r = rec(p, tree, f.slot >> kPathShift);
-        f.c = f_count(p, r)[k];
-        f.vs = f_vsum(p, r)[k];
-        f.rw = f_reward(p, r)[k];
+        const BackSlot b = f_back(p, rec(p, tree, f.slot >> kPathShift))[f.slot & (kMaxActions - 1)];
+        f.vs = b.vsum;
+        f.rw = b.reward;
     }
     return f;
 }
 
+// Node.update_value (agent.py:119-123) on slot k of record r, plus what select will want of it next time.
+// c_old/vs_old: the slot before (vs_old ignored for an unvisited slot); rw: the node's reward.
+__device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, int c_old, double vs_old, double vin,
+                                            float rw, bool leaf, int nb, double& mn_l, double& mx_l) {
+    const int c = c_old + 1;
+    const double vs = (c_old > 0 ? vs_old : 0.0) + vin;
+    f_count(p, r)[k] = c;
+    BackSlot* b = f_back(p, r) + k;
+    if (leaf) {                                   // the leaf: now expanded (agent.py:156-157)
+        BackSlot nbk;
+        nbk.vsum = vs;
+        nbk.reward = rw;
+        nbk.pad = 0;
+        *b = nbk;
+        f_child(p, r)[k] = nb;
+    } else {
+        b->vsum = vs;
+    }
+    const double mean = vs / (double)c;
+    if (mean > mx_l) mx_l = mean;                 // MinMaxStats.update, utils.py:63-66
+    if (mean < mn_l) mn_l = mean;
+    // ucb_score's exploitation term of this child (agent.py:188), normalised here when the bounds are known
+    const double ex = (mean == mean) ? (double)rw + p.discount * mean : p.default_value;
+    f_q(p, r)[k] = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
+}
+
 // pol_row: this tree's A priors or logits (global or LDS); rnew, value_f32: its scalarised reward and value.
+// lds_row: kSumLdsRow floats of LDS owned by this wavefront (G == 64, LOGITS, A <= kSumLdsMax), or nullptr.
 template <int G, bool LOGITS>
 __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, int nb, const float* pol_row,
-                              float rnew, float value_f32, const BackupPrefetch& pf) {
+                              float rnew, float value_f32, const BackupPrefetch& pf, float* lds_row = nullptr) {
     const int A = p.A;
     const int len = pf.len;
     double v = active ? (double)value_f32 : 0.0;
@@ -278,6 +441,20 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             char* r = rec(p, tree, nb);
             f_count(p, r)[gl] = 0;
             f_prior(p, r)[gl] = x / total;
+        }
+    } else if (LOGITS && G == 64 && lds_row != nullptr && A <= kSumLdsMax) {
+        // one wavefront per tree: exp terms staged in this wavefront's LDS row, summed there in NumPy's order
+        for (int k = gl; k < A; k += G) lds_row[k] = active ? expf(pol_row[k]) : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float total = numpy_sum_lds(p, lds_row, lds_row + kSumLdsMax, gl);
+        if (active) {
+            char* r = rec(p, tree, nb);
+            int* cnt = f_count(p, r);
+            float* pr = f_prior(p, r);
+            for (int k = gl; k < A; k += G) {
+                cnt[k] = 0;
+                pr[k] = lds_row[k] / total;                               // network.py:146
+            }
         }
     } else {
         if (active) {
@@ -294,7 +471,9 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             char* r = rec(p, active ? tree : 0, active ? nb : 0);
-            float total = numpy_sum_f32<G>(p, f_prior(p, r), f_reward(p, r), active ? gl : 1 << 30);
+            // the child-block field of a fresh record is unused until the first backup through a slot: scratch
+            float total = numpy_sum_f32<G>(p, f_prior(p, r), reinterpret_cast<float*>(f_child(p, r)),
+                                           active ? gl : 1 << 30);
             if (active) {
                 float* pr = f_prior(p, r);
                 for (int k = gl; k < A; k += G) pr[k] = pr[k] / total;   // network.py:146
@@ -317,21 +496,9 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (gl == j) vin = v;
             if (j < len) v = (double)rj + p.discount * v;
         }
-        if (has) {
-            const int k = pf.slot & (kMaxActions - 1);
-            char* r = rec(p, tree, pf.slot >> kPathShift);
-            const int c = pf.c + 1;                   // Node.update_value, agent.py:119-123
-            const double vs = (pf.c > 0 ? pf.vs : 0.0) + vin;
-            f_count(p, r)[k] = c;
-            f_vsum(p, r)[k] = vs;
-            const double mean = vs / (double)c;
-            if (mean > mx_l) mx_l = mean;             // MinMaxStats.update, utils.py:63-66
-            if (mean < mn_l) mn_l = mean;
-            if (gl == top) {                          // the leaf: now expanded (agent.py:156-157)
-                f_child(p, r)[k] = nb;
-                f_reward(p, r)[k] = rnew;
-            }
-        }
+        if (has)
+            backup_slot(p, rec(p, tree, pf.slot >> kPathShift), pf.slot & (kMaxActions - 1), pf.c, pf.vs, vin, rw,
+                        gl == top, nb, mn_l, mx_l);
     } else {
         // long paths: groups of G positions from the leaf down, lane j of a round owns position top-base-j
         for (int base = 0;; base += G) {
@@ -344,12 +511,13 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             float rw = 0.f;
             char* r = nullptr;
             if (has) {
-                const int slot = p.path[(size_t)tree * (p.N + 1) + pos];
-                k = slot & (kMaxActions - 1);
-                r = rec(p, tree, slot >> kPathShift);
-                c = f_count(p, r)[k];
-                if (c > 0) vs = f_vsum(p, r)[k];
-                rw = (pos == top) ? rnew : f_reward(p, r)[k];
+                const int2 pe = p.path[(size_t)tree * (p.N + 1) + pos];
+                k = pe.x & (kMaxActions - 1);
+                r = rec(p, tree, pe.x >> kPathShift);
+                c = pe.y;
+                const BackSlot b = f_back(p, r)[k];
+                vs = b.vsum;
+                rw = (pos == top) ? rnew : b.reward;
             }
             const int n_here = more ? min(G, len - base) : 0;
             double vin = v;
@@ -359,19 +527,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
                 if (gl == j) vin = v;
                 if (j < n_here) v = (double)rj + p.discount * v;
             }
-            if (has) {
-                c += 1;
-                vs = vs + vin;
-                f_count(p, r)[k] = c;
-                f_vsum(p, r)[k] = vs;
-                const double mean = vs / (double)c;
-                if (mean > mx_l) mx_l = mean;
-                if (mean < mn_l) mn_l = mean;
-                if (pos == top) {
-                    f_child(p, r)[k] = nb;
-                    f_reward(p, r)[k] = rnew;
-                }
-            }
+            if (has) backup_slot(p, r, k, c, vs, vin, rw, pos == top, nb, mn_l, mx_l);
         }
     }
     if (active && gl == 0) {                          // the root (reward None -> chain ends, agent.py:195)
@@ -386,13 +542,9 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         p.sims[tree] += 1;
     }
     if (!p.has_bounds) {
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            const double omx = __shfl_xor(mx_l, off, G);
-            const double omn = __shfl_xor(mn_l, off, G);
-            if (omx > mx_l) mx_l = omx;
-            if (omn < mn_l) mn_l = omn;
-        }
+        // NaN means never enter mx_l / mn_l (the comparisons above are false), so these are plain reductions
+        mx_l = group_minmax_f64<G, true>(mx_l);
+        mn_l = group_minmax_f64<G, false>(mn_l);
         if (active && gl == 0) {
             if (mx_l > p.mm_max[tree]) p.mm_max[tree] = mx_l;
             if (mn_l < p.mm_min[tree]) p.mm_min[tree] = mn_l;
