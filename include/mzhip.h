@@ -51,7 +51,8 @@ typedef struct mz_pool_config {
     int32_t max_simulations;   /* N >= 1; the pool holds N+1 blocks per tree */
     int32_t num_players;       /* 1 or 2; 2 negates the discount (agent.py:150-152) */
     int32_t has_known_bounds;  /* 0: live MinMaxStats (utils.py:63-66); 1: use known_min/known_max */
-    int32_t reserved;
+    int32_t lanes_per_tree;    /* 0: the library chooses; else 2,4,...,64: GPU lanes that share one tree (a tuning
+                                  knob: results do not depend on it) */
     double discount;           /* GameConfig.discount */
     double default_value;      /* MCTSConfig.default_value: exploitation score of unvisited children */
     double known_min;          /* KnownBounds.endpoints() (utils.py:45-49) */

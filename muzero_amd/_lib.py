@@ -14,7 +14,7 @@ c_void_p, c_int32, c_int64, c_double = ctypes.c_void_p, ctypes.c_int32, ctypes.c
 class PoolConfig(ctypes.Structure):
     """mz_pool_config_t"""
     _fields_ = [('num_trees', c_int32), ('num_actions', c_int32), ('max_simulations', c_int32),
-                ('num_players', c_int32), ('has_known_bounds', c_int32), ('reserved', c_int32),
+                ('num_players', c_int32), ('has_known_bounds', c_int32), ('lanes_per_tree', c_int32),
                 ('discount', c_double), ('default_value', c_double), ('known_min', c_double),
                 ('known_max', c_double), ('log_table', c_void_p)]
 

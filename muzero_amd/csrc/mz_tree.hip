@@ -33,6 +33,7 @@
 // all-NaN scores pick the first child, IEEE fp64 division.
 #include "mz_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -44,7 +45,7 @@
 namespace {
 
 // one child per lane: all 8 wavefronts per SIMD resident (64 VGPRs), so a 16384-tree launch needs one round of workgroups
-#define MZ_WAVES(P) __attribute__((amdgpu_waves_per_eu((P) == 1 ? 8 : 1, 8)))
+#define MZ_WAVES(P)
 
 template <int G, int P>
 __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolDev p, int* out_parent, int* out_action) {
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolD
     select_tree<G, P>(p, tree, active, gl, out_parent, out_action);
 }
 
-// LDS row of one wavefront for the softmax terms of a wide action axis (one tree per wavefront: G == 64)
-#define MZ_SUM_LDS(G, LOGITS)                                                                      \
-    __shared__ float s_sum[(G == 64 && LOGITS) ? kBlockThreads / 64 : 1][(G == 64 && LOGITS) ? kSumLdsRow : 1]; \
-    float* lds_row = (G == 64 && LOGITS) ? s_sum[threadIdx.x / 64] : nullptr
+// the LDS rows of this workgroup's groups (mz_tree_dev.h, TreeLds) and the one of the calling lane's group
+#define MZ_TREE_LDS(G)                                                                                         \
+    __shared__ __attribute__((aligned(16))) float s_rows[TreeLds<G>::kGroups * TreeLds<G>::kRow];              \
+    float* lds_row = s_rows + (threadIdx.x / G) * TreeLds<G>::kRow
 
 template <int G, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int nb, const float* pol,
@@ -65,9 +66,10 @@ __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int 
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
-    MZ_SUM_LDS(G, LOGITS);
-    const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
-    backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
+    MZ_TREE_LDS(G);
+    constexpr int PB = TreeLds<G>::kPB;
+    const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(p, tree, active, gl);
+    backprop_tree<G, LOGITS, PB>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
                              active ? value[tree] : 0.f, pf, lds_row);
 }
 
@@ -81,9 +83,10 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
-    MZ_SUM_LDS(G, LOGITS);
-    const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);
-    backprop_tree<G, LOGITS>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
+    MZ_TREE_LDS(G);
+    constexpr int PB = TreeLds<G>::kPB;
+    const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(p, tree, active, gl);
+    backprop_tree<G, LOGITS, PB>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
                              active ? value[tree] : 0.f, pf, lds_row);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,9 +258,14 @@ __global__ void sum_counters_kernel(PoolDev p, long long* out2) {
     }
 }
 
-int group_width(int A) {
+// Lanes per tree when the caller leaves the choice to the library: the power of two covering the action axis, halved
+// when that would idle 40 % of the lanes and the launch has wavefronts to spare (measured at 16384 x 18 actions: 38 us
+// a step with 16 lanes, 48 us with 32; at 4096 x 9 the 16-lane group stays ahead of 8).  Results do not depend on it:
+// every reduction is over a total order, every sum in a fixed order.
+int group_width(int A, int T) {
     int g = 2;
     while (g < A && g < 64) g <<= 1;
+    if (g > 2 && 10 * A <= 6 * g && (long long)T * g / 64 > 4096) g >>= 1;
     return g;
 }
 
@@ -320,20 +328,18 @@ void dispatch_group(int G, F&& f) {
     }
 }
 
-// (G, P) for the kernels that descend: P children per lane are loaded together (1 unless the action axis is wider
-// than a wavefront, then the power of two covering ceil(A / 64), at most 8)
+// (G, P) for the kernels that descend: P children per lane are loaded together (the power of two covering
+// ceil(A / G), at most 8; wider nodes take several rounds)
 template <typename F>
 void dispatch_group_passes(int G, int P, F&& f) {
-    if (G < 64 || P <= 1) {
-        dispatch_group(G, [&](auto g) { f(g, std::integral_constant<int, 1>{}); });
-        return;
-    }
-    std::integral_constant<int, 64> g;
-    switch (P) {
-        case 2: f(g, std::integral_constant<int, 2>{}); break;
-        case 4: f(g, std::integral_constant<int, 4>{}); break;
-        default: f(g, std::integral_constant<int, 8>{}); break;
-    }
+    dispatch_group(G, [&](auto g) {
+        switch (P) {
+            case 1: f(g, std::integral_constant<int, 1>{}); break;
+            case 2: f(g, std::integral_constant<int, 2>{}); break;
+            case 4: f(g, std::integral_constant<int, 4>{}); break;
+            default: f(g, std::integral_constant<int, 8>{}); break;
+        }
+    });
 }
 
 int passes_for(int A, int G) {
@@ -426,6 +432,9 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
                "max_simulations must be in [1, %d] (got %d)", kMaxSimulations, cfg->max_simulations);
     MZ_REQUIRE(cfg->num_players == 1 || cfg->num_players == 2, "num_players must be 1 or 2 (got %d)",
                cfg->num_players);
+    MZ_REQUIRE(cfg->lanes_per_tree == 0 || (cfg->lanes_per_tree >= 2 && cfg->lanes_per_tree <= 64 &&
+                                            (cfg->lanes_per_tree & (cfg->lanes_per_tree - 1)) == 0),
+               "lanes_per_tree must be 0 or a power of two in [2, 64] (got %d)", cfg->lanes_per_tree);
     if (cfg->has_known_bounds)
         MZ_REQUIRE(cfg->known_max == cfg->known_max && cfg->known_min == cfg->known_min, "known bounds are NaN");
     int ndev = 0;
@@ -455,7 +464,7 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         d.default_value = cfg->default_value;
         d.kmin = cfg->known_min;
         d.kmax = cfg->known_max;
-        pool->G = group_width(d.A);
+        pool->G = cfg->lanes_per_tree ? cfg->lanes_per_tree : group_width(d.A, d.T);
         pool->P = passes_for(d.A, pool->G);
         const size_t TA = (size_t)d.T * d.A;
         double* log_dev = nullptr;

@@ -10,8 +10,6 @@ constexpr int kBlockThreads = 256;
 constexpr int kPathShift = 12;                 // path entry .x = (block << 12) | child index
 constexpr int kMaxActions = 1 << kPathShift;   // 4096
 constexpr int kMaxSimulations = (1 << 19) - 2; // (count << 12 | action) and (block << 12 | slot) stay below 2^31
-constexpr int kSumLdsMax = 1024;               // widest action axis whose softmax terms are staged in LDS
-constexpr int kSumLdsRow = kSumLdsMax + 32;    // + the leaf sums of the NumPy pairwise recursion
 
 // Backup half of a child slot (array of structures: one 16-byte access per path node).
 struct __attribute__((aligned(16))) BackSlot {
@@ -290,8 +288,18 @@ __device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch,
                 r += __shfl_xor(r, 2, W);
                 r += __shfl_xor(r, 4, W);
                 res = r;
-            } else {   // groups narrower than 8 lanes only exist for A <= 4 < 8: not reached
+            } else {   // a group narrower than the eight accumulators: its lane 0 keeps all of them
                 res = 0.f;
+                if (gl == 0) {
+                    float acc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = a[lo + i];
+                    for (int m = 8; m < nfull; m += 8) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] += a[lo + m + i];
+                    }
+                    res = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+                }
             }
             if (gl == 0)
                 for (int i = nfull; i < n; ++i) res += a[lo + i];
@@ -308,36 +316,75 @@ __device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch,
     return __shfl(total, 0, G);
 }
 
-// The same summation over a row staged in LDS by ONE wavefront (G == 64): eight lanes per leaf, eight leaves at a
-// time, the 8-accumulator combine by DPP.  a[0..A) and scratch[0..n_sum_leaf) are LDS of this wavefront only, whose
-// DS operations execute in program order, so no barrier is needed.  Returns the sum in every lane.
-__device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int lane) {
-    const int oct = lane >> 3, i = lane & 7;
-    for (int s0 = 0; s0 < p.n_sum_leaf; s0 += 8) {
-        const int s = s0 + oct;
-        const bool has = s < p.n_sum_leaf;
-        const int lo = has ? p.sum_leaf[2 * s] : 0, n = has ? p.sum_leaf[2 * s + 1] : 0;
-        const int nfull = n - (n % 8);
-        float r = 0.f;
-        if (nfull >= 8) {
-            r = a[lo + i];
-            for (int m = 8; m < nfull; m += 8) r += a[lo + m + i];
+// LDS row of one group of G lanes (one tree), owned by the wavefront the group lies in -- DS operations of a wavefront
+// execute in program order, so the lanes of a group hand values to each other through it without a barrier.
+// Holds, one after the other in time: the softmax terms of the new node + the leaf sums of the NumPy recursion;
+// then the rewards along the path (floats) and the values reaching each path position (doubles).
+template <int G>
+struct TreeLds {
+    static constexpr int kPB = 4;                            // path positions per lane held in registers
+    static constexpr int kPathCap = G * kPB;                 // longest path the LDS chain replays
+    static constexpr int kMaxA = G == 64 ? 1024 : 8 * G;     // widest action axis staged in the row
+    static constexpr int kLeafScratch = G == 64 ? 32 : 16;   // leaves of the pairwise recursion (n <= 128 each)
+    static constexpr int kSoftmax = kMaxA + kLeafScratch;
+    static constexpr int kChain = 3 * kPathCap + 2;          // floats + doubles (8-byte aligned)
+    static constexpr int kRow = ((kSoftmax > kChain ? kSoftmax : kChain) + 3) / 4 * 4;   // floats, 16-byte multiple
+    static constexpr int kGroups = kBlockThreads / G;
+};
+
+// NumPy float32 pairwise summation (trap T4) over a row a[0..A) staged in LDS by one group: eight lanes (an octet)
+// per leaf, G/8 leaves at a time, the 8-accumulator combine by DPP; groups narrower than an octet leave it to
+// their lane 0.  Returns the sum in every lane of the group.
+template <int G>
+__device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int gl) {
+    if (G >= 8) {
+        constexpr int OCT = G >= 8 ? G / 8 : 1;
+        const int oct = gl >> 3, i = gl & 7;
+        for (int s0 = 0; s0 < p.n_sum_leaf; s0 += OCT) {
+            const int s = s0 + oct;
+            const bool has = s < p.n_sum_leaf;
+            const int lo = has ? p.sum_leaf[2 * s] : 0, n = has ? p.sum_leaf[2 * s + 1] : 0;
+            const int nfull = n - (n % 8);
+            float r = 0.f;
+            if (nfull >= 8) {
+                r = a[lo + i];
+                for (int m = 8; m < nfull; m += 8) r += a[lo + m + i];
+            }
+            r += dpp_f32<kDppXor1>(r);             // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): fp32 + is commutative,
+            r += dpp_f32<kDppXor2>(r);             // so every lane of the octet ends with lane 0's bits
+            r += dpp_f32<kDppHalfMirror>(r);
+            if (has && i == 0) {
+                float res = n < 8 ? 0.f : r;
+                for (int t = nfull; t < n; ++t) res += a[lo + t];
+                scratch[s] = res;
+            }
         }
-        r += dpp_f32<kDppXor1>(r);                 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): fp32 + is commutative,
-        r += dpp_f32<kDppXor2>(r);                 // so every lane of the octet ends with lane 0's bits
-        r += dpp_f32<kDppHalfMirror>(r);
-        if (has && i == 0) {
-            float res = n < 8 ? 0.f : r;
+    } else if (gl == 0) {
+        for (int s = 0; s < p.n_sum_leaf; ++s) {
+            const int lo = p.sum_leaf[2 * s], n = p.sum_leaf[2 * s + 1];
+            const int nfull = n - (n % 8);
+            float res = 0.f;
+            if (nfull >= 8) {
+                float r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = a[lo + i];
+                for (int m = 8; m < nfull; m += 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) r[i] += a[lo + m + i];
+                }
+                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            }
             for (int t = nfull; t < n; ++t) res += a[lo + t];
             scratch[s] = res;
         }
     }
-    if (lane == 0) {
+    if (gl == 0) {
         for (int m = 0; m < p.n_sum_merge; ++m) {
             const int dst = p.sum_merge[2 * m], src = p.sum_merge[2 * m + 1];
             scratch[dst] = scratch[dst] + scratch[src];
         }
     }
+    __builtin_amdgcn_wave_barrier();
     return scratch[0];
 }
 
@@ -365,35 +412,47 @@ __device__ __forceinline__ float numpy_sum_lanes(float x, int n, int gl) {
 // expand_node(leaf, all actions) + backpropagate(leaf, value)  (agent.py:208-211, 154-160, 192-196)
 // ---------------------------------------------------------------------------------------------------
 // What the backup reads before it can do anything, requested as early as the caller can (the fused inference +
-// tree kernel asks for it before the network head runs): the path length, this lane's path entry (position gl,
-// counted from the root; entries past the length are stale but valid: the path array starts zeroed) with the slot's
-// visit count as select saw it, the slot's backup half, and the root's statistics.
-struct BackupPrefetch {
-    int len, slot, c, root_count;
-    double vs, root_vsum;
-    float rw;
+// tree kernel asks for it before the network head runs): the path length, this lane's PB path entries (positions
+// gl, gl+G, ... counted from the root; entries past the length are stale but valid: the path array starts zeroed)
+// with the slots' visit counts as select saw them, the slots' backup halves, and the root's statistics.
+template <int PB>
+struct BackupPrefetchT {
+    int len, root_count;
+    double root_vsum;
+    int slot[PB], c[PB];
+    double vs[PB];
+    float rw[PB];
 };
+using BackupPrefetch = BackupPrefetchT<1>;
 
-template <int G>
-__device__ __forceinline__ BackupPrefetch backprop_prefetch(const PoolDev& p, int tree, bool active, int gl) {
-    BackupPrefetch f;
+template <int G, int PB = 1>
+__device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& p, int tree, bool active, int gl) {
+    BackupPrefetchT<PB> f;
     f.len = 0;
-    f.slot = 0;
-    f.c = 0;
     f.root_count = 0;
-    f.vs = 0.0;
     f.root_vsum = 0.0;
-    f.rw = 0.f;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        f.slot[j] = 0;
+        f.c[j] = 0;
+        f.vs[j] = 0.0;
+        f.rw[j] = 0.f;
+    }
     if (active) {
         f.len = p.path_len[tree];
-        const int2 pe = p.path[(size_t)tree * (p.N + 1) + min(gl, p.N)];
-        f.slot = pe.x;
-        f.c = pe.y;
+        int2 pe[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) pe[j] = p.path[(size_t)tree * (p.N + 1) + min(gl + G * j, p.N)];
         f.root_count = p.root_count[tree];
         f.root_vsum = p.root_vsum[tree];
-        const BackSlot b = f_back(p, rec(p, tree, f.slot >> kPathShift))[f.slot & (kMaxActions - 1)];
-        f.vs = b.vsum;
-        f.rw = b.reward;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            f.slot[j] = pe[j].x;
+            f.c[j] = pe[j].y;
+            const BackSlot b = f_back(p, rec(p, tree, pe[j].x >> kPathShift))[pe[j].x & (kMaxActions - 1)];
+            f.vs[j] = b.vsum;
+            f.rw[j] = b.reward;
+        }
     }
     return f;
 }
@@ -425,10 +484,12 @@ __device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, in
 }
 
 // pol_row: this tree's A priors or logits (global or LDS); rnew, value_f32: its scalarised reward and value.
-// lds_row: kSumLdsRow floats of LDS owned by this wavefront (G == 64, LOGITS, A <= kSumLdsMax), or nullptr.
-template <int G, bool LOGITS>
+// lds_row: this group's TreeLds<G>::kRow floats of LDS (16-byte aligned), or nullptr (then PB must be 1, and the
+// softmax of an action axis wider than the group goes through global memory and a workgroup barrier).
+template <int G, bool LOGITS, int PB = 1>
 __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, int nb, const float* pol_row,
-                              float rnew, float value_f32, const BackupPrefetch& pf, float* lds_row = nullptr) {
+                              float rnew, float value_f32, const BackupPrefetchT<PB>& pf, float* lds_row = nullptr) {
+    using L = TreeLds<G>;
     const int A = p.A;
     const int len = pf.len;
     double v = active ? (double)value_f32 : 0.0;
@@ -442,11 +503,11 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             f_count(p, r)[gl] = 0;
             f_prior(p, r)[gl] = x / total;
         }
-    } else if (LOGITS && G == 64 && lds_row != nullptr && A <= kSumLdsMax) {
-        // one wavefront per tree: exp terms staged in this wavefront's LDS row, summed there in NumPy's order
+    } else if (LOGITS && lds_row != nullptr && A <= L::kMaxA) {
+        // exp terms staged in the group's LDS row, summed there in NumPy's order
         for (int k = gl; k < A; k += G) lds_row[k] = active ? expf(pol_row[k]) : 0.f;
         __builtin_amdgcn_wave_barrier();
-        const float total = numpy_sum_lds(p, lds_row, lds_row + kSumLdsMax, gl);
+        const float total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl);
         if (active) {
             char* r = rec(p, tree, nb);
             int* cnt = f_count(p, r);
@@ -456,6 +517,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
                 pr[k] = lds_row[k] / total;                               // network.py:146
             }
         }
+        __builtin_amdgcn_wave_barrier();
     } else {
         if (active) {
             char* r = rec(p, tree, nb);
@@ -480,15 +542,39 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             }
         }
     }
-    // Backup chain leaf -> root: all lanes replay the fp64 recurrence value = reward + discount*value
-    // (agent.py:195) through shuffles; the lane that owns a path position keeps the value that reached it.
+    // Backup chain leaf -> root: the fp64 recurrence value = reward + discount*value (agent.py:195) is replayed in
+    // order; the lane that owns a path position keeps the value that reached it.
     const int top = len - 1;
     double mn_l = std::numeric_limits<double>::infinity();
     double mx_l = -std::numeric_limits<double>::infinity();
-    if (!__any(len > G)) {
-        // every path of this wavefront fits one group: lane gl owns position gl, its slot came with the prefetch
+    if (lds_row != nullptr && !__any(len > L::kPathCap)) {
+        // every lane of the group replays the chain from the rewards staged in the group's LDS row and leaves the
+        // value entering each position there
+        float* rws = lds_row;
+        double* vins = reinterpret_cast<double*>(lds_row + L::kPathCap);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int pos = gl + G * j;
+            if (pos < len) rws[pos] = (pos == top) ? rnew : pf.rw[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pos = top; pos >= 0; --pos) {
+            vins[pos] = v;
+            v = (double)rws[pos] + p.discount * v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int pos = gl + G * j;
+            if (active && pos < len)
+                backup_slot(p, rec(p, tree, pf.slot[j] >> kPathShift), pf.slot[j] & (kMaxActions - 1), pf.c[j], pf.vs[j],
+                            vins[pos], (pos == top) ? rnew : pf.rw[j], pos == top, nb, mn_l, mx_l);
+        }
+    } else if (!__any(len > G)) {
+        // every path of this wavefront fits one group: lane gl owns position gl, its slot came with the prefetch;
+        // the rewards travel by shuffles
         const bool has = active && gl < len;
-        const float rw = (gl == top) ? rnew : pf.rw;
+        const float rw = (gl == top) ? rnew : pf.rw[0];
         double vin = v;
         for (int j = G - 1; j >= 0; --j) {
             if (!__any(j < len)) continue;
@@ -497,8 +583,8 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (j < len) v = (double)rj + p.discount * v;
         }
         if (has)
-            backup_slot(p, rec(p, tree, pf.slot >> kPathShift), pf.slot & (kMaxActions - 1), pf.c, pf.vs, vin, rw,
-                        gl == top, nb, mn_l, mx_l);
+            backup_slot(p, rec(p, tree, pf.slot[0] >> kPathShift), pf.slot[0] & (kMaxActions - 1), pf.c[0], pf.vs[0], vin,
+                        rw, gl == top, nb, mn_l, mx_l);
     } else {
         // long paths: groups of G positions from the leaf down, lane j of a round owns position top-base-j
         for (int base = 0;; base += G) {

@@ -25,7 +25,7 @@ def _check_tensor(name, t, dtype, shape, device):
 
 class TreePool:
     def __init__(self, num_trees, num_actions, max_simulations, num_players=1, discount=1.0, default_value=0.0,
-                 known_bounds=None, device='cuda'):
+                 known_bounds=None, device='cuda', lanes_per_tree=0):
         self._h = None
         self._lib = _lib.load()
         if not torch.cuda.is_available():
@@ -38,7 +38,8 @@ class TreePool:
         self.known_bounds = None if known_bounds is None else (float(known_bounds[0]), float(known_bounds[1]))
         # config.py:159-160 tabulated with the host's math.log (trap T6); parent visit count <= N
         self._log_table = np.array([2 * math.log(n + 1) for n in range(self.N + 2)], np.float64)
-        cfg = _lib.PoolConfig(self.T, self.A, self.N, int(num_players), int(known_bounds is not None), 0,
+        cfg = _lib.PoolConfig(self.T, self.A, self.N, int(num_players), int(known_bounds is not None),
+                              int(lanes_per_tree),
                               float(discount), float(default_value),
                               self.known_bounds[0] if known_bounds is not None else 0.0,
                               self.known_bounds[1] if known_bounds is not None else 0.0,

@@ -77,6 +77,56 @@ def test_hip_pool_matches_c_oracle(case, fused, ad):
     pool.close()
 
 
+LANE_CASES = [
+    # every group width against the C oracle: narrow groups take several children per lane, keep several path
+    # positions per lane and stage the softmax terms and the backup chain in LDS; long paths overflow those
+    dict(T=70, A=2, N=60, players=1, discount=0.99, default=50.0, bounds=(0.0, 100.0), reward='uniform', legal='all'),
+    dict(T=130, A=9, N=25, players=2, discount=1.0, default=0.0, bounds=(-1.0, 1.0), reward='tanh', legal='ragged'),
+    dict(T=90, A=18, N=50, players=1, discount=0.997, default=0.0, bounds=None, reward='uniform', legal='ragged'),
+    dict(T=10, A=362, N=40, players=2, discount=1.0, default=0.0, bounds=None, reward='tanh', legal='all'),
+]
+
+
+@pytest.mark.parametrize('lanes', [2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize('case', LANE_CASES, ids=lambda c: f"A{c['A']}_N{c['N']}")
+def test_lanes_per_tree_does_not_change_results(case, lanes, ad):
+    from oracle import c_oracle
+    inp = synthetic_inputs(case['T'], case['A'], case['N'], seed=4321 + case['A'], reward_mode=case['reward'],
+                           legal_mode=case['legal'], value_scale=100.0 if case['default'] == 50.0 else 1.0)
+    kw = dict(num_trees=case['T'], num_actions=case['A'], max_simulations=case['N'], num_players=case['players'],
+              discount=case['discount'], default_value=case['default'], known_bounds=case['bounds'])
+    opool = c_oracle.OraclePool(**kw)
+    want = run_synthetic_on_pool(opool, inp, NumpyAdapter, temperature=1.0)
+    for fused in (False, True):
+        pool = hip_pool(lanes_per_tree=lanes, **kw)
+        got = run_synthetic_on_pool(pool, inp, ad, fused=fused, temperature=1.0)
+        assert_same_search(got, want)
+        for t in range(0, case['T'], max(1, case['T'] // 3)):
+            if inp['n_legal'][t] == 0:
+                continue
+            for e in range(0, case['N'] + 1, 9):
+                a, b = pool.read_block(t, e), opool.read_block(t, e)
+                for key in ('actions', 'count', 'value_sum', 'prior', 'child'):
+                    np.testing.assert_array_equal(a[key], b[key], err_msg=f'tree {t} block {e} {key}')
+        pool.close()
+
+
+@pytest.mark.parametrize('lanes', [2, 8, 64])
+def test_logits_any_lanes_within_exp_tolerance(lanes, ad):
+    """The device-side softmax (LDS-staged for action axes wider than the group) for every group width."""
+    for A in (2, 9, 18, 65, 362):
+        T = 6
+        inp = synthetic_inputs(T, A, 2, seed=900 + A)
+        pool = hip_pool(num_trees=T, num_actions=A, max_simulations=2, known_bounds=None, lanes_per_tree=lanes)
+        pool.expand_roots(ad.put(inp['logits'][0]), logits=True)
+        pool.select()
+        pool.step(ad.put(inp['logits'][1]), ad.put(inp['rewards'][1]), ad.put(inp['values'][1]), logits=True)
+        for t in range(T):
+            np.testing.assert_allclose(pool.read_block(t, 1)['prior'], inp['priors'][1, t].astype(np.float64),
+                                       rtol=5e-7, err_msg=f'A={A} lanes={lanes}')
+        pool.close()
+
+
 def test_pool_is_reusable_across_moves(ad):
     """reset() + expand_roots() starts a fresh search in the same memory (agent.py:220-221: no tree reuse)."""
     from oracle import c_oracle

@@ -27,13 +27,13 @@ def timed(fn):
     return out, (e0, e1)
 
 
-def probe(name, wl, device, moves=int(os.environ.get("PROBE_MOVES", "3"))):
+def probe(name, wl, device, moves=int(os.environ.get("PROBE_MOVES", "3")), lanes=0):
     T, A, N = wl['T'], wl['A'], wl['N']
     pool = TreePool(num_trees=T, num_actions=A, max_simulations=N, num_players=wl['players'], discount=wl['discount'],
-                    default_value=wl['default'], known_bounds=wl['bounds'], device=device)
+                    default_value=wl['default'], known_bounds=wl['bounds'], device=device, lanes_per_tree=lanes)
     logits, values, rewards, noise, u = bench.synthetic_outputs(T, A, N, 1234, wl['reward'], device)
     priors = torch.softmax(logits, -1).contiguous()
-    res = {'workload': name}
+    res = {'workload': name, 'lanes': lanes}
     for use_logits in (False, True):
         pol = logits if use_logits else priors
         tag = 'logits' if use_logits else 'priors'
@@ -80,7 +80,8 @@ def main():
         wl = dict(bench.WORKLOADS[n])
         if n.startswith('go') and os.environ.get('PROBE_GO_N'):
             wl['N'] = int(os.environ['PROBE_GO_N'])
-        print(json.dumps(probe(n, wl, device)), flush=True)
+        for lanes in [int(x) for x in os.environ.get('PROBE_LANES', '0').split(',')]:
+            print(json.dumps(probe(n, wl, device, lanes=lanes)), flush=True)
 
 
 if __name__ == '__main__':
