@@ -65,41 +65,76 @@ def synthetic_outputs(T, A, N, seed, reward, device):
 
 
 class SyntheticTreeMove:
-    """One move of T searches with injected outputs (tree kernels only; workloads without a reference network)."""
+    """One move of T searches with injected outputs (tree kernels only; workloads without a reference network).  The T
+    trees of a GPU are split into `lanes` pools stepped on separate HIP streams (trees are independent): a step of one
+    pool ends with its deepest tree, and the other pools' launches fill the chip meanwhile.  Every pool's move is
+    enqueued by one native call (mz_search_move_injected)."""
     dominant = 'step_kernel'
     bound = 'hbm'
 
-    def __init__(self, wl, device, seed):
+    def __init__(self, wl, device, seed, lanes=1):
         from muzero_amd.tree_pool import TreePool
-        self.wl = wl
-        self.pool = TreePool(num_trees=wl['T'], num_actions=wl['A'], max_simulations=wl['N'],
-                             num_players=wl['players'], discount=wl['discount'], default_value=wl['default'],
-                             known_bounds=wl['bounds'], device=device)
+        assert wl['T'] % lanes == 0, 'lanes must divide the trees per GPU'
+        self.wl, self.device, self.nl = wl, device, lanes
+        Tl = wl['T'] // lanes
         self.logits, self.values, self.rewards, self.noise, self.u = synthetic_outputs(
             wl['T'], wl['A'], wl['N'], seed, wl['reward'], device)
         self.temperature = torch.ones(wl['T'], dtype=torch.float64, device=device)
-        self.events = []
-        self.counters = self.pool.counters
-        self.trees_per_launch = wl['T']
+        self.lanes = []
+        for i in range(lanes):
+            sl = slice(i * Tl, (i + 1) * Tl)
+            stream = torch.cuda.Stream(device=device) if lanes > 1 else torch.cuda.current_stream(device)
+            with torch.cuda.stream(stream):
+                pool = TreePool(num_trees=Tl, num_actions=wl['A'], max_simulations=wl['N'], num_players=wl['players'],
+                                discount=wl['discount'], default_value=wl['default'], known_bounds=wl['bounds'],
+                                device=device)
+            self.lanes.append(dict(pool=pool, stream=stream, logits=self.logits[:, sl].contiguous(),
+                                   values=self.values[:, sl].contiguous(), rewards=self.rewards[:, sl].contiguous(),
+                                   noise=self.noise[sl].contiguous(), u=self.u[sl].contiguous(),
+                                   temperature=self.temperature[sl].contiguous()))
+        if lanes > 1:
+            del self.logits, self.values, self.rewards
+        torch.cuda.synchronize()
+        self.hip_events = HipEvents()
+        self.event_sets = []
+        self.trees_per_launch = Tl
+
+    def counters(self):
+        return sum(np.asarray(l['pool'].counters()) for l in self.lanes)
 
     def run(self, timed_events=False):
-        pool, N = self.pool, self.wl['N']
-        pool.reset()
-        pool.expand_roots(self.logits[0], logits=True)
-        pool.add_root_noise(self.noise, 0.25)
-        pool.select()
-        for s in range(N - 1):
-            if timed_events:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            pool.step(self.logits[s + 1], self.rewards[s + 1], self.values[s + 1], logits=True)
-            if timed_events:
-                e1.record()
-                self.events.append((e0, e1))
-        pool.expand_backprop(self.logits[N], self.rewards[N], self.values[N], logits=True)
-        stats = pool.root_stats()
-        action = pool.select_action(self.u, self.temperature)
-        return stats, action
+        import ctypes
+        N = self.wl['N']
+        main = torch.cuda.current_stream(self.device)
+        out = []
+        if self.nl > 1:
+            for l in self.lanes:
+                l['stream'].wait_stream(main)
+        for i, l in enumerate(self.lanes):
+            events = None
+            if timed_events and i == 0 and N > 1:     # HIP events around lane 0's fused steps, on its stream
+                events = (ctypes.c_void_p * (2 * (N - 1)))()
+                for j in range(2 * (N - 1)):
+                    events[j] = self.hip_events.new()
+                self.event_sets.append(events)
+            with torch.cuda.stream(l['stream']):
+                pool = l['pool']
+                pool.search_injected(l['logits'], l['rewards'], l['values'], noise=l['noise'], frac=0.25, logits=True,
+                                     events=events)
+                out.append((pool.root_stats(), pool.select_action(l['u'], l['temperature'])))
+        if self.nl > 1:
+            for l in self.lanes:
+                main.wait_stream(l['stream'])
+        return out
+
+    def step_durations(self):
+        """mean duration (s) of the fused step launches of lane 0 over the sampled timed steps"""
+        import ctypes
+        ms = []
+        for events in self.event_sets:
+            for j in range(0, len(events), 2):
+                ms.append(self.hip_events.elapsed_ms(ctypes.c_void_p(events[j]), ctypes.c_void_p(events[j + 1])))
+        return float(np.mean(ms)) * 1e-3 if ms else None
 
 
 class HipEvents:
@@ -317,7 +352,8 @@ def main():
         wl['T'] = args.trees
     with_net = wl['net'] is not None and not args.inject
     # per-rank seeds: every rank searches different games
-    move = NetworkMove(wl, device, 1234 + rank, world, args.lanes) if with_net else SyntheticTreeMove(wl, device, 1234 + rank)
+    move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes) if with_net
+            else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes))
 
     for _ in range(args.warmup):
         move.run()
@@ -366,12 +402,13 @@ def main():
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         network = f"{wl['net']} network, random-init weights, fp32 MFMA"
     else:
-        ms = [a.elapsed_time(b) for a, b in move.events]
-        avg = float(np.mean(ms)) * 1e-3
+        avg = move.step_durations()
         achieved = tree_bytes_launch / avg / 1e9
         roofline = {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_us': avg * 1e6,
                     'bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d}
+        # all lanes together: algorithmic bytes of every simulation of the timed region over its wall time
+        extra = {'aggregate_algorithmic_GBps': sims_rank * bytes_per_simulation(wl['A'], mean_d, wl['A']) / elapsed / 1e9}
         network = 'injected outputs (tree kernels only)'
 
     if rank == 0:
@@ -380,7 +417,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if with_net else 'f64',
             'data': 'synthetic',
-            'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'lanes_per_gpu': args.lanes if with_net else 1,
+            'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'lanes_per_gpu': args.lanes,
                        'actions': wl['A'],
                        'simulations_per_move': wl['N'], 'network': network,
                        'sharding': f'{world} independent game shards (one rank per GPU)' +

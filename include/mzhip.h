@@ -238,6 +238,20 @@ typedef struct mz_move_io {
  * the loop, root statistics and action sampling -- about 2N+6 (TicTacToe) or 3N+6 launches on the stream, no host synchronisation. */
 int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
 
+/* The tree half of one move against a network whose outputs are given: run_mcts (agent.py:198-211) with
+ * recurrent_inference replaced by table look-ups, the way the reference's MCTS is exercised with a stub network and the
+ * way the tree kernels are measured alone.  Root expansion (+noise when noise != NULL), then N simulations as N+1
+ * launches on the pool's stream, no host synchronisation; root statistics / action sampling are the caller's next calls.
+ *   policy [N+1, T, A] f32 device: row 0 the root's masked policy, row s the policy of simulation s's new node
+ *                                  (logits when is_logits != 0, see mz_expand_backprop_logits)
+ *   reward, value [N+1, T] f32 device (row 0 unused); legal/n_legal as mz_expand_roots; noise as mz_add_root_noise
+ *   parent_block, action [T] i32 device workspaces (the last select's outputs)
+ *   events: NULL, or HOST array of 2*(N-1) hipEvent_t recorded before and after each fused step (measurement only) */
+int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations, const float* policy, int32_t is_logits,
+                            const float* reward, const float* value, const int32_t* legal, const int32_t* n_legal,
+                            const double* noise, double noise_frac, int32_t* parent_block, int32_t* action,
+                            void** events);
+
 /* ---- batched environments on the device (the callers either side of a move) --------------- *
  * State is caller-owned SoA over num_games games; every call enqueues one launch on `stream` (a hipStream_t).
  * A finished game is frozen: step leaves it untouched and observe reports n_legal = 0, which mz_expand_roots

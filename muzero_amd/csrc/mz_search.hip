@@ -4,6 +4,7 @@
 // as ~2N+6 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
+#include "mz_pool_internal.h"
 
 extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io) {
     MZ_REQUIRE(pool && net && io, "pool/net/io is NULL");
@@ -37,6 +38,40 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
     MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
     if (io->out_action) MZ_TRY_(mz_select_action(pool, io->u, io->temperature, io->out_action));
+#undef MZ_TRY_
+    return MZ_OK;
+}
+
+extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations, const float* policy, int32_t is_logits,
+                                       const float* reward, const float* value, const int32_t* legal,
+                                       const int32_t* n_legal, const double* noise, double noise_frac,
+                                       int32_t* parent_block, int32_t* action, void** events) {
+    MZ_REQUIRE(pool && policy && reward && value && parent_block && action, "pool/policy/reward/value/workspaces is NULL");
+    const int N = num_simulations;
+    MZ_REQUIRE(N >= 1 && N <= pool->dev.N, "num_simulations must be in [1, %d] (got %d)", pool->dev.N, N);
+    const size_t T = (size_t)pool->dev.T, TA = T * (size_t)pool->dev.A;
+#define MZ_TRY_(expr)               \
+    do {                            \
+        int s_ = (expr);            \
+        if (s_ != MZ_OK) return s_; \
+    } while (0)
+    MZ_TRY_(mz_pool_reset(pool));
+    MZ_TRY_(is_logits ? mz_expand_roots_logits(pool, policy, legal, n_legal) : mz_expand_roots(pool, policy, legal, n_legal));
+    if (noise) MZ_TRY_(mz_add_root_noise(pool, noise, noise_frac));
+    MZ_TRY_(mz_select(pool, parent_block, action));
+    for (int s = 1; s <= N; ++s) {
+        const float* pol = policy + (size_t)s * TA;
+        const float* rw = reward + (size_t)s * T;
+        const float* vl = value + (size_t)s * T;
+        if (s == N) {
+            MZ_TRY_(is_logits ? mz_expand_backprop_logits(pool, pol, rw, vl) : mz_expand_backprop(pool, pol, rw, vl));
+            break;
+        }
+        if (events) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1)]), pool->stream));
+        MZ_TRY_(is_logits ? mz_step_logits(pool, pol, rw, vl, parent_block, action)
+                          : mz_step(pool, pol, rw, vl, parent_block, action));
+        if (events) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1) + 1]), pool->stream));
+    }
 #undef MZ_TRY_
     return MZ_OK;
 }

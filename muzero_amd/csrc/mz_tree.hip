@@ -21,8 +21,8 @@
 // Block e is the node expanded by simulation e-1 in every tree (lockstep), block 0 is the root.  Only visit_count
 // and prior are initialised at expansion; q/child/value_sum/reward of a slot are written by the first backup
 // through it (visited <=> expanded) and never read before.
-// Root priors are fp64 after the noise mix (agent.py:175) and live in root_prior[T][A] with the root's
-// action list root_action[T][A].
+// Root priors are fp64 after the noise mix (agent.py:175) and live in root_prior[T][A]; the root's action list is
+// the act field of its slots.
 //
 // Execution.  One group of G lanes per tree, G = the power of two >= A (2..64): 64/G trees per wavefront,
 // lanes stride over the children, (score, action) arg-max by __shfl_xor inside the group.  Every tree keeps
@@ -49,10 +49,12 @@ namespace {
 
 template <int G, int P>
 __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolDev p, int* out_parent, int* out_action) {
+    __shared__ double s_log[kLogLds];
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
-    select_tree<G, P>(p, tree, active, gl, out_parent, out_action);
+    const LdsLog lds_log = stage_log_table(p, s_log);
+    select_tree<G, P>(p, tree, active, gl, out_parent, out_action, lds_log);
 }
 
 // the LDS rows of this workgroup's groups (mz_tree_dev.h, TreeLds) and the one of the calling lane's group
@@ -60,17 +62,43 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolD
     __shared__ __attribute__((aligned(16))) float s_rows[TreeLds<G>::kGroups * TreeLds<G>::kRow];              \
     float* lds_row = s_rows + (threadIdx.x / G) * TreeLds<G>::kRow
 
+// What a backup needs of its tree, all requested together: whether it is active, the prefetch, the network's outputs.
+template <int G, int PB>
+struct BackupInputs {
+    bool active;
+    BackupPrefetchT<PB> pf;
+    float reward, value;
+    const float* pol_row;
+};
+template <int G, int PB>
+__device__ __forceinline__ BackupInputs<G, PB> backup_inputs(const PoolDev& p, int tree, int gl, const float* pol,
+                                                             const float* reward, const float* value) {
+    BackupInputs<G, PB> b;
+    const bool in = tree < p.T;
+    const int tc = in ? tree : 0;
+    const int n_root = p.n_root[tc];
+    b.pf = backprop_prefetch<G, PB>(p, tc, in, gl);
+    b.reward = reward[tc];
+    b.value = value[tc];
+    b.pol_row = pol + (size_t)tc * p.A;
+    b.active = in && n_root > 0;
+    if (!b.active) {
+        b.pf.len = 0;
+        b.reward = 0.f;
+        b.value = 0.f;
+    }
+    return b;
+}
+
 template <int G, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int nb, const float* pol,
                                                                  const float* reward, const float* value) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
-    const bool active = tree < p.T && p.n_root[tree] > 0;
     MZ_TREE_LDS(G);
     constexpr int PB = TreeLds<G>::kPB;
-    const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(p, tree, active, gl);
-    backprop_tree<G, LOGITS, PB>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f, pf, lds_row);
+    const BackupInputs<G, PB> b = backup_inputs<G, PB>(p, tree, gl, pol, reward, value);
+    backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb, b.pol_row, b.reward, b.value, b.pf, lds_row);
 }
 
 // expand+backprop of simulation s fused with select of simulation s+1.  A tree's group lies inside one wavefront, whose
@@ -80,17 +108,17 @@ template <int G, int P, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev p, int nb, const float* pol,
                                                              const float* reward, const float* value,
                                                              int* out_parent, int* out_action) {
+    __shared__ double s_log[kLogLds];
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
-    const bool active = tree < p.T && p.n_root[tree] > 0;
     MZ_TREE_LDS(G);
     constexpr int PB = TreeLds<G>::kPB;
-    const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(p, tree, active, gl);
-    backprop_tree<G, LOGITS, PB>(p, tree, active, gl, nb, pol + (size_t)(active ? tree : 0) * p.A, active ? reward[tree] : 0.f,
-                             active ? value[tree] : 0.f, pf, lds_row);
+    const BackupInputs<G, PB> b = backup_inputs<G, PB>(p, tree, gl, pol, reward, value);
+    const LdsLog lds_log = stage_log_table(p, s_log);
+    backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb, b.pol_row, b.reward, b.value, b.pf, lds_row);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    select_tree<G, P>(p, tree, active, gl, out_parent, out_action);
+    select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
 }
 
 // Root expansion (agent.py:154-160 on the root; positional priors, trap T5).
@@ -110,40 +138,41 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
         }
     }
     char* r = rec(p, in ? tree : 0, 0);
+    // staging for the exp terms over the FULL action axis + the leaf sums: the root's backup half, unused until the
+    // first backup
+    float* stage = reinterpret_cast<float*>(f_back(p, r));
     float total = 1.f;
     if (LOGITS) {
         // masked_policy over the FULL action axis (network.py:143-146): exp(logit) at legal actions, 0 elsewhere
-        if (in && n > 0) {
-            float* pr = f_prior(p, r);
-            for (int k = gl; k < A; k += G) pr[k] = 0.f;
-        }
+        if (in && n > 0)
+            for (int k = gl; k < A; k += G) stage[k] = 0.f;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (in && n > 0) {
-            float* pr = f_prior(p, r);
             for (int k = gl; k < n; k += G) {
                 const int a = legal ? legal[(size_t)tree * A + k] : k;
-                if (a >= 0 && a < A) pr[a] = expf(pol[(size_t)tree * A + a]);
+                if (a >= 0 && a < A) stage[a] = expf(pol[(size_t)tree * A + a]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        total = numpy_sum_f32<G>(p, f_prior(p, r), reinterpret_cast<float*>(f_child(p, r)), (in && n > 0) ? gl : 1 << 30);
+        total = numpy_sum_f32<G>(p, stage, stage + A, (in && n > 0) ? gl : 1 << 30);
     }
     if (!in) return;
-    int* cnt = f_count(p, r);
+    Slot* slots = f_slots(p, r);
     for (int k = gl; k < n; k += G) {
         int a = legal ? legal[(size_t)tree * A + k] : k;
         if (a < 0 || a >= A) {
             a = 0;
             atomicOr(p.err_flag, 4);
         }
-        cnt[k] = 0;
-        const float pk = LOGITS ? f_prior(p, r)[k] / total : pol[(size_t)tree * A + k];   // child k <- policy[k]
+        const float pk = LOGITS ? stage[k] / total : pol[(size_t)tree * A + k];   // child k <- policy[k] (trap T5)
+        slots[k].count = 0;
+        slots[k].prior = pk;
+        slots[k].act = a;
         p.root_prior[(size_t)tree * A + k] = (double)pk;
-        p.root_action[(size_t)tree * A + k] = a;
     }
     if (gl == 0) {
         p.n_root[tree] = n;
@@ -172,10 +201,10 @@ __global__ void root_stats_kernel(PoolDev p, int* visits, double* root_value, do
         for (int a = 0; a < A; ++a) visits[(size_t)tree * A + a] = 0;
     if (policy)
         for (int a = 0; a < A; ++a) policy[(size_t)tree * A + a] = 0.f;
-    const int* cnt = f_count(p, rec(p, tree, 0));
+    const Slot* slots = f_slots(p, rec(p, tree, 0));
     for (int k = 0; k < n; ++k) {
-        const int a = p.root_action[(size_t)tree * A + k];
-        const int c = cnt[k];
+        const int a = slots[k].act;
+        const int c = slots[k].count;
         if (visits) visits[(size_t)tree * A + a] = c;
         if (policy) policy[(size_t)tree * A + a] = (float)((double)c / (double)rc);    // agent.py:230
     }
@@ -191,18 +220,19 @@ __global__ void root_stats_kernel(PoolDev p, int* visits, double* root_value, do
 __global__ void select_action_kernel(PoolDev p, const double* u, const double* temperature, int* out_action) {
     const int tree = blockIdx.x * blockDim.x + threadIdx.x;
     if (tree >= p.T) return;
-    const int A = p.A, n = p.n_root[tree];
+    const int n = p.n_root[tree];
     if (n <= 0) {
         out_action[tree] = -1;
         return;
     }
-    const int* cnt = f_count(p, rec(p, tree, 0));
-    const int* act = p.root_action + (size_t)tree * A;
+    const Slot* slots = f_slots(p, rec(p, tree, 0));
+    auto cnt = [&](int k) { return slots[k].count; };
+    auto act = [&](int k) { return slots[k].act; };
     const double t = temperature[tree];
     if (t == 0.0) {                               // max((count, action)): ties to the largest action
-        int bc = cnt[0], ba = act[0];
+        int bc = cnt(0), ba = act(0);
         for (int k = 1; k < n; ++k) {
-            const int c = cnt[k], a = act[k];
+            const int c = cnt(k), a = act(k);
             if (c > bc || (c == bc && a > ba)) {
                 bc = c;
                 ba = a;
@@ -222,17 +252,17 @@ __global__ void select_action_kernel(PoolDev p, const double* u, const double* t
         return pow((double)c, inv_t);
     };
     double total = 0.0;                           // itertools.accumulate: sequential fp64 sums
-    for (int k = 0; k < n; ++k) total = (k == 0) ? weight(cnt[0]) : total + weight(cnt[k]);
+    for (int k = 0; k < n; ++k) total = (k == 0) ? weight(cnt(0)) : total + weight(cnt(k));
     const double x = u[tree] * (total + 0.0);
     // bisect_right(cum, x, 0, n-1) == number of cum[i] <= x for i < n-1 (cum is non-decreasing)
     double cum = 0.0;
     int idx = 0;
     for (int k = 0; k < n - 1; ++k) {
-        cum = (k == 0) ? weight(cnt[0]) : cum + weight(cnt[k]);
+        cum = (k == 0) ? weight(cnt(0)) : cum + weight(cnt(k));
         if (!(x < cum)) idx = k + 1;
         else break;
     }
-    out_action[tree] = act[idx];
+    out_action[tree] = act(idx);
 }
 
 __global__ void sum_counters_kernel(PoolDev p, long long* out2) {
@@ -457,8 +487,9 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         d.A = cfg->num_actions;
         d.N = cfg->max_simulations;
         d.has_bounds = cfg->has_known_bounds ? 1 : 0;
-        d.off_back = (20 * d.A + 15) / 16 * 16;
-        d.RS = (d.off_back + 16 * d.A + 127) / 128 * 128;
+        d.off_back = ((int)sizeof(Slot) * d.A + 15) / 16 * 16;
+        d.RS = (d.off_back + (int)sizeof(BackSlot) * d.A + 127) / 128 * 128;
+        d.hi_unsorted = d.A - 1 < kMaxActions - 1 ? (d.A > 1 ? d.A - 1 : 1) : kMaxActions - 1;
         d.tree_stride = (size_t)(d.N + 1) * (size_t)d.RS;
         d.discount = cfg->num_players == 2 ? -cfg->discount : cfg->discount;      // agent.py:150-152
         d.default_value = cfg->default_value;
@@ -472,7 +503,6 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         int* merge_dev = nullptr;
         if ((status = dev_alloc(pool, &d.blocks, (size_t)d.T * d.tree_stride)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &d.root_prior, TA)) != MZ_OK) break;
-        if ((status = dev_alloc(pool, &d.root_action, TA)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &d.n_root, (size_t)d.T)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &d.root_count, (size_t)d.T)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &d.root_vsum, (size_t)d.T)) != MZ_OK) break;
@@ -488,6 +518,14 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         std::vector<double> table(d.N + 2);
         for (int n = 0; n < d.N + 2; ++n)
             table[n] = cfg->log_table ? cfg->log_table[n] : 2 * std::log((double)(n + 1));   // config.py:160
+        // Children kept by descending prior, so that select reads a prefix of a node (mz_tree_dev.h, select_tree): sound
+        // when the exploration factor is finite and >= 0 (it is 2 log(n+1) unless the caller's table says otherwise) and
+        // worth it when ranking a new node's children is cheap.  MZ_TREE_NO_SORT=1 switches it off (profiling aid).
+        bool table_ok = true;
+        for (double x : table) table_ok = table_ok && x >= 0.0 && std::isfinite(x);
+        const int per_lane = (d.A + pool->G - 1) / pool->G;
+        const char* no_sort = std::getenv("MZ_TREE_NO_SORT");
+        d.sort_nodes = (table_ok && d.A >= 4 && d.A * per_lane <= 512 && !(no_sort && no_sort[0] == '1')) ? 1 : 0;
         std::vector<int> leaves, merges;
         build_sum_program(0, d.A, leaves, merges);
         d.n_sum_leaf = (int)leaves.size() / 2;
@@ -656,27 +694,38 @@ int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* ou
     std::vector<char> recbuf(d.RS);
     MZ_HIP(hipMemcpy(recbuf.data(), d.blocks + (size_t)tree * d.tree_stride + (size_t)block * d.RS, d.RS,
                      hipMemcpyDeviceToHost));
-    const int* cnt = reinterpret_cast<const int*>(recbuf.data() + 8 * (size_t)A);
-    const float* pr = reinterpret_cast<const float*>(recbuf.data() + 12 * (size_t)A);
-    const int* ch = reinterpret_cast<const int*>(recbuf.data() + 16 * (size_t)A);
+    const Slot* slots = reinterpret_cast<const Slot*>(recbuf.data());
     const BackSlot* back = reinterpret_cast<const BackSlot*>(recbuf.data() + d.off_back);
     std::vector<double> rprior(A);
-    std::vector<int> ract(A);
-    if (block == 0) {
+    if (block == 0)
         MZ_HIP(hipMemcpy(rprior.data(), d.root_prior + (size_t)tree * A, A * sizeof(double), hipMemcpyDeviceToHost));
-        MZ_HIP(hipMemcpy(ract.data(), d.root_action + (size_t)tree * A, A * sizeof(int), hipMemcpyDeviceToHost));
-    }
-    for (int k = 0; k < n; ++k) {
-        const bool visited = cnt[k] > 0;
-        if (actions) actions[k] = block == 0 ? ract[k] : k;
-        if (count) count[k] = cnt[k];
-        if (value_sum) value_sum[k] = visited ? back[k].vsum : 0.0;
-        if (prior) prior[k] = block == 0 ? rprior[k] : (double)pr[k];
-        if (reward) reward[k] = visited ? back[k].reward : std::numeric_limits<float>::quiet_NaN();
-        if (child) child[k] = visited ? ch[k] : -1;
+    for (int s = 0; s < n; ++s) {
+        // children in insertion order: the root's slots are in it; below the root slot s holds action slots[s].act
+        const int k = block == 0 ? s : slots[s].act;
+        if (k < 0 || k >= n) return mz::fail(MZ_ERR_STATE, "corrupt record: slot %d holds action %d", s, k);
+        const bool visited = slots[s].count > 0;
+        if (actions) actions[k] = block == 0 ? slots[s].act : k;
+        if (count) count[k] = slots[s].count;
+        if (value_sum) value_sum[k] = visited ? back[s].vsum : 0.0;
+        if (prior) prior[k] = block == 0 ? rprior[s] : (double)slots[s].prior;
+        if (reward) reward[k] = visited ? back[s].reward : std::numeric_limits<float>::quiet_NaN();
+        if (child) child[k] = visited ? (slots[s].child_hi & kChildMask) : -1;
     }
     return MZ_OK;
 }
+
+#ifdef MZ_TREE_TRACE
+// experiment builds only: copies out and clears the per-wavefront phase counters of mz_tree_dev.h
+int mz_debug_tree_trace(uint32_t* out, int64_t out_bytes) {
+    MZ_HIP(hipDeviceSynchronize());
+    MZ_REQUIRE(out_bytes == (int64_t)sizeof(unsigned) * kTraceWaves * 2 * kTracePhases, "trace buffer size");
+    MZ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_trace), (size_t)out_bytes));
+    void* sym = nullptr;
+    MZ_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tree_trace)));
+    MZ_HIP(hipMemset(sym, 0, (size_t)out_bytes));
+    return MZ_OK;
+}
+#endif
 
 int mz_pool_num_blocks(mz_pool_t* pool) { return pool ? pool->blocks_in_use : 0; }
 

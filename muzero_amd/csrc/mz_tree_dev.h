@@ -11,7 +11,24 @@ constexpr int kPathShift = 12;                 // path entry .x = (block << 12) 
 constexpr int kMaxActions = 1 << kPathShift;   // 4096
 constexpr int kMaxSimulations = (1 << 19) - 2; // (count << 12 | action) and (block << 12 | slot) stay below 2^31
 
-// Backup half of a child slot (array of structures: one 16-byte access per path node).
+// Select half of a child slot.  A record is Slot[A] followed by BackSlot[A].
+//   Root record (block 0): slot k is the k-th listed legal action (insertion order; prior unused: the root's priors
+//   are fp64 after the noise mix and live in root_prior).
+//   Other records: slot 0 is action 0 (the first child in insertion order, whose NaN score decides Python's max);
+//   slots 1..A-1 hold the other actions by descending prior when the node is `sorted`, else in action order.
+struct __attribute__((aligned(8))) Slot {
+    double q;         // exploitation term of ucb_score for a visited child (see backup_slot); garbage when count == 0
+    int count;        // Node.visit_count (agent.py:113)
+    float prior;      // Node.prior (agent.py:110)
+    int child_hi;     // (hi << 20) | block of the child node, written when the child is expanded;
+                      //   hi = 1 + the largest visited slot of THAT node (>= 1), kept up to date by select
+    int act;          // the action of this slot
+};
+static_assert(sizeof(Slot) == 24, "Slot layout");
+constexpr int kChildBits = 20;                 // block index < 2^20 (kMaxSimulations), hi <= 4095
+constexpr int kChildMask = (1 << kChildBits) - 1;
+
+// Backup half of a child slot (one 16-byte access per path node).
 struct __attribute__((aligned(16))) BackSlot {
     double vsum;      // Node.value_sum (agent.py:112)
     float reward;     // Node.reward (agent.py:156)
@@ -23,10 +40,11 @@ struct PoolDev {
     int has_bounds;
     int RS;                    // record stride in bytes (multiple of 128)
     int off_back;              // byte offset of the BackSlot array inside a record
+    int sort_nodes;            // new nodes keep their children by descending prior (select reads a prefix)
+    int hi_unsorted;           // hi of an unsorted node: min(A-1, 4095), i.e. always scan everything
     size_t tree_stride;        // (N+1)*RS
     char* blocks;
     double* root_prior;        // [T][A]
-    int* root_action;          // [T][A]
     int* n_root;               // [T]
     int* root_count;           // [T]
     double* root_vsum;         // [T]
@@ -44,18 +62,10 @@ struct PoolDev {
     double discount, default_value, kmin, kmax;
 };
 
-// Record of one expanded node (block e of tree t), A child slots:
-//   select half, structure of arrays:  q f64[A] | visit_count i32[A] | prior f32[A] | child i32[A]      (20*A bytes)
-//   backup half, array of structures:  { value_sum f64, reward f32, pad } [A] at off_back               (16*A bytes)
-// q is what ucb_score needs of a visited child, computed once per backup instead of once per look:
-//   reward + discount*value (agent.py:188), and with known bounds already MinMaxStats.normalize'd (utils.py:68-76).
 __device__ __forceinline__ char* rec(const PoolDev& p, int tree, int e) {
     return p.blocks + (size_t)tree * p.tree_stride + (size_t)e * (size_t)p.RS;
 }
-__device__ __forceinline__ double* f_q(const PoolDev& p, char* r) { return reinterpret_cast<double*>(r); }
-__device__ __forceinline__ int* f_count(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 8 * (size_t)p.A); }
-__device__ __forceinline__ float* f_prior(const PoolDev& p, char* r) { return reinterpret_cast<float*>(r + 12 * (size_t)p.A); }
-__device__ __forceinline__ int* f_child(const PoolDev& p, char* r) { return reinterpret_cast<int*>(r + 16 * (size_t)p.A); }
+__device__ __forceinline__ Slot* f_slots(const PoolDev& p, char* r) { return reinterpret_cast<Slot*>(r); }
 __device__ __forceinline__ BackSlot* f_back(const PoolDev& p, char* r) { return reinterpret_cast<BackSlot*>(r + p.off_back); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -125,126 +135,248 @@ __device__ __forceinline__ int group_max_i32(int x) {
 __device__ __forceinline__ void pin(int& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
 
+// Phase timing for experiment builds (-DMZ_TREE_TRACE, tools/tree_trace.py): lane 0 of every wavefront adds the shader
+// clocks since its previous stamp to g_tree_trace[phase] after draining its memory operations.  Compiles to nothing in
+// the library.
+#ifdef MZ_TREE_TRACE
+constexpr int kTraceWaves = 1 << 15, kTracePhases = 12;
+__device__ unsigned g_tree_trace[kTraceWaves][2 * kTracePhases];    // per wavefront: clocks, then stamp counts
+struct TreeTrace {
+    long long t;
+    unsigned clk[kTracePhases], cnt[kTracePhases];
+    __device__ TreeTrace() : t(clock64()) {
+        for (int i = 0; i < kTracePhases; ++i) clk[i] = cnt[i] = 0;
+    }
+    __device__ __forceinline__ void stamp(int phase) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const long long now = clock64();
+#pragma unroll
+        for (int i = 0; i < kTracePhases; ++i)
+            if (i == phase) {
+                clk[i] += (unsigned)(now - t);
+                cnt[i] += 1;
+            }
+        t = clock64();
+    }
+    __device__ ~TreeTrace() {
+        const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+        if ((threadIdx.x & 63) == 0 && wave < kTraceWaves)
+            for (int i = 0; i < kTracePhases; ++i)
+                if (cnt[i]) {
+                    g_tree_trace[wave][i] += clk[i];
+                    g_tree_trace[wave][kTracePhases + i] += cnt[i];
+                }
+    }
+};
+#define MZ_TRACE_DECL TreeTrace mz_trace_
+#define MZ_TRACE(phase) mz_trace_.stamp(phase)
+#else
+#define MZ_TRACE_DECL
+#define MZ_TRACE(phase)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
-// select_leaf (agent.py:177-190) for one tree by a group of G lanes; lane gl scores children gl, gl+G, ...  Every
+// select_leaf (agent.py:177-190) for one tree by a group of G lanes; lane gl scores slots gl, gl+G, ...  Every
 // lane of the wavefront calls this (inactive lanes with active=false): the reductions are wave-wide instructions.
-// P = children per lane whose loads are in flight together (P*G >= A for one round trip per level).
+// P = slots per lane whose loads are in flight together.
+//
+// At the root every listed child is scored.  Below it a sorted node is scored over a prefix: with hi = 1 + its
+// largest visited slot, slots [0, hi+2) hold every visited child, slot 0, and the two unvisited children of largest
+// prior.  An unvisited child scores normalize(default) + prior*(2 log(Np+1)), non-decreasing in the prior (IEEE
+// rounding is monotone, the factor is >= 0: checked when the pool is created), so no slot past the prefix can beat
+// the last slot of the prefix; it can only TIE with it, and ties go to the largest action, so the prefix grows
+// while its last slot's score is not strictly below the best one.  Bit-identical to scoring every child.
 // ---------------------------------------------------------------------------------------------------
-template <int G, int P = 1>
-__device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int* out_parent, int* out_action) {
+// The exploration table 2*log(n+1), n <= N+1, staged in LDS by the whole workgroup when it fits (a descent then reads
+// nothing but slots from global memory).  Returns the LDS table or nullptr; contains a workgroup barrier.
+constexpr int kLogLds = 1024;
+typedef const __attribute__((address_space(3))) double* LdsLog;   // typed as LDS: never merged with a global pointer
+__device__ __forceinline__ LdsLog stage_log_table(const PoolDev& p, double* s_log) {
+    if (p.N + 2 > kLogLds) return nullptr;
+    for (int i = threadIdx.x; i < p.N + 2; i += blockDim.x) s_log[i] = p.log_table[i];
+    __syncthreads();
+    return (LdsLog)s_log;
+}
+
+struct SelectNorm {                // MinMaxStats.normalize as this select call sees it (utils.py:68-76)
+    double na, nd, dflt;           // (x - na) / nd; dflt: the normalised default value of an unvisited child
+    bool renorm;                   // q holds raw reward + discount*value (bounds unknown and max != min)
+};
+struct LevelWinner {
+    int k;                         // winning slot
+    int cc;                        // (its visit count << 12) | its action
+    int ch;                        // its child word
+};
+
+// One node: scores slots [0, target) -- growing the prefix while its last slot ties with the best -- with PP slots per
+// lane in flight, and returns the winner in every lane of the group.  Wave-wide: lanes of groups that are `done`
+// come along idle.
+template <int G, int PP, bool ROOT>
+__device__ __forceinline__ LevelWinner scan_level(const PoolDev& p, int tree, int gl, bool done, const Slot* slots,
+                                                  int np_, LdsLog lds_log, const SelectNorm& nm, int target) {
     const int A = p.A;
-    int e = 0, np_ = 0, nchild = 0, depth = 0;
+    const int gbase = (int)(threadIdx.x & 63u) & ~(G - 1);   // first lane of this group in the wavefront
+    const unsigned long long gbits = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    const double ninf = -std::numeric_limits<double>::infinity();
+    double bs = ninf;
+    int bkey = -1, bcc = 0, bch = 0;         // local best: key, (count << 12 | action), child word
+    int s0nan = 0, cc0 = 0, ch0 = 0;         // slot 0 (lane 0 of the group): the winner when its score is NaN
+    double fsc = 0.0;                        // score of the last slot of the prefix, in the lane that owns it
+    double lt = 0.0;                         // 2*log(Np+1), config.py:159-160
+    int scanned = 0;
+    bool scanning = !done;
+    int gkey = -1;
+    for (int round = 0; round <= kMaxActions; ++round) {          // bounded: the prefix grows by >= 1 a round
+        if (!__any(scanning)) break;
+        if (scanning) {
+            // One dependent round trip per level: every slot this lane owns is requested before anything is
+            // computed (q / child of an unvisited slot are garbage and unused), and the winner's count and
+            // child come back through a shuffle, not through a second load.
+            const int base = scanned & ~(G - 1);                  // slot k is always scored by lane k % G
+            const int upto = min(target, base + PP * G);
+            int c[PP], ch[PP], act[PP];
+            double q[PP], pr[PP];
+            if (round == 0) {                                     // in flight with the slots
+                if (lds_log != nullptr) lt = lds_log[np_];
+                else lt = p.log_table[np_];
+            }
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                const int k = min(base + j * G + gl, upto - 1);
+                const Slot s = slots[k];
+                c[j] = s.count;
+                q[j] = s.q;
+                ch[j] = s.child_hi;
+                act[j] = s.act;
+                pr[j] = ROOT ? p.root_prior[(size_t)tree * A + k] : (double)s.prior;
+            }
+            pin(lt);
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                pin(c[j]);
+                pin(q[j]);
+                pin(ch[j]);
+                pin(pr[j]);
+                pin(act[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                const int k = base + j * G + gl;
+                if (k >= scanned && k < upto) {
+                    double x = nm.dflt, ex = lt;                          // unvisited: lt / (0 + 1) == lt
+                    if (c[j] > 0) {
+                        x = nm.renorm ? (q[j] - nm.na) / nm.nd : q[j];    // utils.py:68-76
+                        ex = lt / (double)(c[j] + 1);                     // config.py:160
+                    }
+                    const double sc = x + pr[j] * ex;                     // agent.py:189-190
+                    const int key = (act[j] << 16) | k;
+                    const int cc = (c[j] << kPathShift) | act[j];
+                    if (k == 0) {
+                        s0nan = (sc != sc);
+                        cc0 = cc;
+                        ch0 = ch[j];
+                    }
+                    if (k == target - 1) fsc = sc;
+                    if (sc == sc && (bkey < 0 || sc > bs || (sc == bs && key > bkey))) {
+                        bs = sc;
+                        bkey = key;
+                        bcc = cc;
+                        bch = ch[j];
+                    }
+                }
+            }
+            scanned = upto;
+        }
+        // arg-max over the group: the largest non-NaN score, ties to the largest (action, index) key (trap T1)
+        const double gmax = group_minmax_f64<G, true>(bs);
+        gkey = group_max_i32<G>((bkey >= 0 && bs == gmax) ? bkey : -1);
+        if (ROOT) {
+            if (scanned >= target) scanning = false;
+        } else {
+            // the lane that scored the last slot of the prefix says whether it is strictly below the best
+            const bool tie = gl == ((target - 1) & (G - 1)) && !(fsc < gmax);
+            const bool grow = ((__ballot(tie) >> gbase) & gbits) != 0;
+            if (scanning && scanned >= target) {
+                if (target < A && grow) target = min(A, target + G);      // a tie (or NaN): look further
+                else scanning = false;
+            }
+        }
+    }
+    // Python's max() over (score, action, child) tuples never replaces a NaN-scored first element and never
+    // accepts a NaN-scored later one (agent.py:184): NaN first child wins, else the non-NaN arg-max.
+    const bool first_wins = ((__ballot(s0nan != 0) >> gbase) & 1ull) != 0 || gkey < 0;
+    LevelWinner w;
+    w.k = first_wins ? 0 : (gkey & 0xffff);
+    const int owner = first_wins ? 0 : (w.k & (G - 1));
+    w.cc = __shfl(first_wins ? cc0 : bcc, owner, G);
+    w.ch = __shfl(first_wins ? ch0 : bch, owner, G);
+    return w;
+}
+
+// lds_log: the pool's log table staged in LDS (see stage_log_table), or nullptr to read it from global memory.
+template <int G, int P = 1>
+__device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int* out_parent, int* out_action,
+                            LdsLog lds_log = nullptr) {
+    const int A = p.A;
+    int e = 0, np_ = 0, target = 0, depth = 0, hi = 0;
+    int* hi_home = nullptr;        // where the current node's (hi, block) word lives: its parent's slot
+    int hi_word = 0;
     bool done = !active;
     bool ident = false;            // MinMaxStats.normalize returns the value unchanged (utils.py:71-72)
-    double na = p.kmin, nd = p.kmax - p.kmin;
+    SelectNorm nm;
+    nm.na = p.kmin;
+    nm.nd = p.kmax - p.kmin;
     if (active) {
         np_ = p.root_count[tree];
-        nchild = p.n_root[tree];
+        target = p.n_root[tree];
         if (!p.has_bounds) {
             const double mn = p.mm_min[tree], mx = p.mm_max[tree];
             ident = (mx == mn);
-            na = mn;
-            nd = mx - mn;
+            nm.na = mn;
+            nm.nd = mx - mn;
         }
     }
     // isnan(child.value) -> the default value, normalised like any other (agent.py:188, utils.py:68-76): the
     // exploitation term of every unvisited child
-    const double dflt = ident ? p.default_value : (p.default_value - na) / nd;
-    const bool renorm = !p.has_bounds && !ident;             // q holds raw reward + discount*value
-    const int gbase = (int)(threadIdx.x & 63u) & ~(G - 1);   // first lane of this group in the wavefront
-    const double ninf = -std::numeric_limits<double>::infinity();
+    nm.dflt = ident ? p.default_value : (p.default_value - nm.na) / nm.nd;
+    nm.renorm = !p.has_bounds && !ident;
+    // the loads above are waited for HERE, not inside the descent (whose waits would otherwise cover its own stores)
+    pin(np_);
+    pin(target);
+    pin(nm.dflt);
+    MZ_TRACE_DECL;
+    MZ_TRACE(8);                                 // select: root statistics loaded
     for (int it = 0; it <= p.N; ++it) {          // a path holds at most N+1 nodes: every wave reaches the exit
         if (!__any(!done)) break;
         const bool root = (it == 0);             // block 0 is only ever the first node of a path
-        double bs = ninf;
-        int bkey = -1, bcc = 0, bch = 0;         // local best: key, (count << 12 | action), child block
-        int s0nan = 0, cc0 = 0, ch0 = 0;         // child 0 (lane 0 of the group): the winner when its score is NaN
-        if (!done) {
-            char* r = rec(p, tree, e);
-            const double* qv = f_q(p, r);
-            const int* cnt = f_count(p, r);
-            const float* prf = f_prior(p, r);
-            const int* chd = f_child(p, r);
-            const double lt = p.log_table[np_];                       // 2*log(Np+1), config.py:159-160
-            for (int base = 0; base < nchild; base += P * G) {
-                // One dependent round trip per level: every field of every child this lane owns is requested
-                // before anything is computed (q / child of an unvisited slot are garbage and unused), and the
-                // winner's count and child block come back through a shuffle, not through a second load.
-                int c[P], ch[P], act[P];
-                double q[P], pr[P];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int k = min(base + j * G + gl, nchild - 1);
-                    c[j] = cnt[k];
-                    q[j] = qv[k];
-                    ch[j] = chd[k];
-                    if (root) {
-                        pr[j] = p.root_prior[(size_t)tree * A + k];
-                        act[j] = p.root_action[(size_t)tree * A + k];
-                    } else {
-                        pr[j] = (double)prf[k];
-                        act[j] = k;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    pin(c[j]);
-                    pin(q[j]);
-                    pin(ch[j]);
-                    pin(pr[j]);
-                    pin(act[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int k = base + j * G + gl;
-                    if (k < nchild) {
-                        double x = dflt, ex = lt;                             // unvisited: lt / (0 + 1) == lt
-                        if (c[j] > 0) {
-                            x = renorm ? (q[j] - na) / nd : q[j];             // utils.py:68-76
-                            ex = lt / (double)(c[j] + 1);                     // config.py:160
-                        }
-                        const double sc = x + pr[j] * ex;                     // agent.py:189-190
-                        const int key = (act[j] << 16) | k;
-                        const int cc = (c[j] << kPathShift) | act[j];
-                        if (k == 0) {
-                            s0nan = (sc != sc);
-                            cc0 = cc;
-                            ch0 = ch[j];
-                        }
-                        if (sc == sc && (bkey < 0 || sc > bs || (sc == bs && key > bkey))) {
-                            bs = sc;
-                            bkey = key;
-                            bcc = cc;
-                            bch = ch[j];
-                        }
-                    }
-                }
-            }
-        }
-        // arg-max over the group: the largest non-NaN score, ties to the largest (action, index) key (trap T1)
-        const double gmax = group_minmax_f64<G, true>(bs);
-        const int gkey = group_max_i32<G>((bkey >= 0 && bs == gmax) ? bkey : -1);
-        // Python's max() over (score, action, child) tuples never replaces a NaN-scored first element and never
-        // accepts a NaN-scored later one (agent.py:184): NaN first child wins, else the non-NaN arg-max.
-        const bool first_wins = ((__ballot(s0nan != 0) >> gbase) & 1ull) != 0 || gkey < 0;
-        const int k = first_wins ? 0 : (gkey & 0xffff);
-        const int owner = first_wins ? 0 : (k & (G - 1));            // child k is scored by lane k % G
-        const int wcc = __shfl(first_wins ? cc0 : bcc, owner, G);
-        const int wchild = __shfl(first_wins ? ch0 : bch, owner, G);
-        const int wc = wcc >> kPathShift;
+        Slot* slots = nullptr;
+        if (!done) slots = f_slots(p, rec(p, tree, e));
+        // the root: every listed child, P per lane; below it a prefix (see above), one slot per lane and round --
+        // unless the pool keeps its nodes unsorted, whose every child is read, again P per lane
+        const LevelWinner w = root           ? scan_level<G, P, true>(p, tree, gl, done, slots, np_, lds_log, nm, target)
+                              : p.sort_nodes ? scan_level<G, 1, false>(p, tree, gl, done, slots, np_, lds_log, nm, target)
+                                             : scan_level<G, P, false>(p, tree, gl, done, slots, np_, lds_log, nm, target);
+        const int k = w.k, wc = w.cc >> kPathShift;
+        MZ_TRACE(root ? 9 : 10);                 // select: one level
         if (!done) {
             if (gl == 0) p.path[(size_t)tree * (p.N + 1) + depth] = make_int2((e << kPathShift) | k, wc);
             if (wc > 0) {                    // visited <=> expanded: descend (agent.py:179-180)
+                hi_home = &slots[k].child_hi;
+                hi_word = w.ch;
                 np_ = wc;
-                e = wchild;
-                nchild = A;
+                e = w.ch & kChildMask;
+                hi = (int)((unsigned)w.ch >> kChildBits);
+                target = min(hi + 2, A);
                 ++depth;
             } else {
                 done = true;
                 if (gl == 0) {
                     out_parent[tree] = e;
-                    out_action[tree] = wcc & (kMaxActions - 1);
+                    out_action[tree] = w.cc & (kMaxActions - 1);
                     p.path_len[tree] = depth + 1;
+                    // this slot is visited once the backup has run: the node's prefix must cover it from now on
+                    if (!root && k + 1 > hi)
+                        *hi_home = (min(k + 1, kMaxActions - 1) << kChildBits) | (hi_word & kChildMask);
                 }
             }
         }
@@ -425,8 +557,10 @@ struct BackupPrefetchT {
 };
 using BackupPrefetch = BackupPrefetchT<1>;
 
+// `in`: the tree exists (tree < T); an inactive tree's entries are read all the same (valid memory, unused), so that
+// nothing here waits for the load that says whether the tree is active.
 template <int G, int PB = 1>
-__device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& p, int tree, bool active, int gl) {
+__device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& p, int tree, bool in, int gl) {
     BackupPrefetchT<PB> f;
     f.len = 0;
     f.root_count = 0;
@@ -438,7 +572,7 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
         f.vs[j] = 0.0;
         f.rw[j] = 0.f;
     }
-    if (active) {
+    if (in) {
         f.len = p.path_len[tree];
         int2 pe[PB];
 #pragma unroll
@@ -460,18 +594,19 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
 // Node.update_value (agent.py:119-123) on slot k of record r, plus what select will want of it next time.
 // c_old/vs_old: the slot before (vs_old ignored for an unvisited slot); rw: the node's reward.
 __device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, int c_old, double vs_old, double vin,
-                                            float rw, bool leaf, int nb, double& mn_l, double& mx_l) {
+                                            float rw, bool leaf, int nb, int hi0, double& mn_l, double& mx_l) {
     const int c = c_old + 1;
     const double vs = (c_old > 0 ? vs_old : 0.0) + vin;
-    f_count(p, r)[k] = c;
+    Slot* s = f_slots(p, r) + k;
     BackSlot* b = f_back(p, r) + k;
+    s->count = c;
     if (leaf) {                                   // the leaf: now expanded (agent.py:156-157)
         BackSlot nbk;
         nbk.vsum = vs;
         nbk.reward = rw;
         nbk.pad = 0;
         *b = nbk;
-        f_child(p, r)[k] = nb;
+        s->child_hi = (hi0 << kChildBits) | nb;
     } else {
         b->vsum = vs;
     }
@@ -480,7 +615,21 @@ __device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, in
     if (mean < mn_l) mn_l = mean;
     // ucb_score's exploitation term of this child (agent.py:188), normalised here when the bounds are known
     const double ex = (mean == mean) ? (double)rw + p.discount * mean : p.default_value;
-    f_q(p, r)[k] = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
+    s->q = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
+}
+
+// A prior the prefix argument of select_tree can rely on: finite and >= 0.
+__device__ __forceinline__ bool regular_prior(float x) { return x >= 0.f && x <= 3.4028234663852886e38f; }
+
+// Slot (1 + rank) of action i >= 1 among actions 1..A-1 by descending (prior, action); pj(j) returns prior j.
+template <typename F>
+__device__ __forceinline__ int sorted_slot(int A, int i, float pi, F&& pj) {
+    int rank = 0;
+    for (int j = 1; j < A; ++j) {
+        const float x = pj(j);
+        rank += (x > pi || (x == pi && j > i)) ? 1 : 0;
+    }
+    return 1 + rank;
 }
 
 // pol_row: this tree's A priors or logits (global or LDS); rnew, value_f32: its scalarised reward and value.
@@ -493,55 +642,91 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
     const int A = p.A;
     const int len = pf.len;
     double v = active ? (double)value_f32 : 0.0;
-    if (LOGITS && A <= G) {
-        // masked_policy over all actions (network.py:142-146): exp, NumPy-ordered fp32 sum, IEEE divide -- one
-        // prior per lane, no trip through memory
-        const float x = (active && gl < A) ? expf(pol_row[gl]) : 0.f;     // no max-subtraction (network.py:145)
-        const float total = numpy_sum_lanes<G>(x, A, gl);
-        if (active && gl < A) {
-            char* r = rec(p, tree, nb);
-            f_count(p, r)[gl] = 0;
-            f_prior(p, r)[gl] = x / total;
+    MZ_TRACE_DECL;
+    MZ_TRACE(1);                                 // backup: prefetch landed
+    // ---- expand_node: the new record's slots (count 0, prior, action), sorted by prior when the pool sorts
+    int hi0 = p.hi_unsorted;                                   // hi of the new node as its parent's slot will hold it
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((threadIdx.x & 63u) & ~(G - 1));
+    if (A <= G) {
+        // one child per lane, entirely in registers
+        float pr = 0.f;
+        if (LOGITS) {
+            // masked_policy over all actions (network.py:142-146): exp, NumPy-ordered fp32 sum, IEEE divide
+            const float x = (active && gl < A) ? expf(pol_row[gl]) : 0.f; // no max-subtraction (network.py:145)
+            const float total = numpy_sum_lanes<G>(x, A, gl);
+            pr = x / total;
+        } else if (active && gl < A) {
+            pr = pol_row[gl];
         }
-    } else if (LOGITS && lds_row != nullptr && A <= L::kMaxA) {
-        // exp terms staged in the group's LDS row, summed there in NumPy's order
-        for (int k = gl; k < A; k += G) lds_row[k] = active ? expf(pol_row[k]) : 0.f;
+        const bool sorted = p.sort_nodes && (__ballot(gl < A && !regular_prior(pr)) & gmask) == 0;
+        int slot = gl;
+        if (sorted) {
+            hi0 = 1;
+            const int s1 = sorted_slot(A, gl, pr, [&](int j) { return __shfl(pr, j, G); });
+            if (gl >= 1) slot = s1;
+        }
+        if (active && gl < A) {
+            Slot* s = f_slots(p, rec(p, tree, nb)) + slot;
+            s->count = 0;
+            s->prior = pr;
+            s->act = gl;
+        }
+    } else if (lds_row != nullptr && A <= L::kMaxA) {
+        // priors staged in the group's LDS row (softmax terms summed there in NumPy's order)
+        for (int k = gl; k < A; k += G) lds_row[k] = !active ? 0.f : LOGITS ? expf(pol_row[k]) : pol_row[k];
         __builtin_amdgcn_wave_barrier();
-        const float total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl);
-        if (active) {
-            char* r = rec(p, tree, nb);
-            int* cnt = f_count(p, r);
-            float* pr = f_prior(p, r);
-            for (int k = gl; k < A; k += G) {
-                cnt[k] = 0;
-                pr[k] = lds_row[k] / total;                               // network.py:146
+        if (LOGITS) {
+            const float total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl);
+            for (int k = gl; k < A; k += G) lds_row[k] = lds_row[k] / total;          // network.py:146
+            __builtin_amdgcn_wave_barrier();
+        }
+        bool bad = false;
+        for (int k = gl; k < A; k += G) bad |= !regular_prior(lds_row[k]);
+        const bool sorted = p.sort_nodes && (__ballot(bad) & gmask) == 0;
+        if (sorted) hi0 = 1;
+        Slot* slots = f_slots(p, rec(p, active ? tree : 0, active ? nb : 0));
+        for (int k = gl; k < A; k += G) {
+            const float pr = lds_row[k];
+            int slot = k;
+            if (sorted && k >= 1) slot = sorted_slot(A, k, pr, [&](int j) { return lds_row[j]; });
+            if (active) {
+                Slot* s = slots + slot;
+                s->count = 0;
+                s->prior = pr;
+                s->act = k;
             }
         }
         __builtin_amdgcn_wave_barrier();
     } else {
-        if (active) {
-            char* r = rec(p, tree, nb);
-            int* cnt = f_count(p, r);
-            float* pr = f_prior(p, r);
-            for (int k = gl; k < A; k += G) {
-                cnt[k] = 0;
-                pr[k] = LOGITS ? expf(pol_row[k]) : pol_row[k];
-            }
-        }
+        // no LDS row, or an action axis wider than it: unsorted slots; softmax terms staged in the new record's
+        // backup half (unused until the first backup through a slot) and summed through global memory
+        char* r = rec(p, active ? tree : 0, active ? nb : 0);
+        float* stage = reinterpret_cast<float*>(f_back(p, r));
         if (LOGITS) {
+            if (active)
+                for (int k = gl; k < A; k += G) stage[k] = expf(pol_row[k]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            char* r = rec(p, active ? tree : 0, active ? nb : 0);
-            // the child-block field of a fresh record is unused until the first backup through a slot: scratch
-            float total = numpy_sum_f32<G>(p, f_prior(p, r), reinterpret_cast<float*>(f_child(p, r)),
-                                           active ? gl : 1 << 30);
+            const float total = numpy_sum_f32<G>(p, stage, stage + A, active ? gl : 1 << 30);
             if (active) {
-                float* pr = f_prior(p, r);
-                for (int k = gl; k < A; k += G) pr[k] = pr[k] / total;   // network.py:146
+                Slot* slots = f_slots(p, r);
+                for (int k = gl; k < A; k += G) {
+                    slots[k].count = 0;
+                    slots[k].prior = stage[k] / total;                    // network.py:146
+                    slots[k].act = k;
+                }
+            }
+        } else if (active) {
+            Slot* slots = f_slots(p, r);
+            for (int k = gl; k < A; k += G) {
+                slots[k].count = 0;
+                slots[k].prior = pol_row[k];
+                slots[k].act = k;
             }
         }
     }
+    MZ_TRACE(2);                                 // backup: new node written
     // Backup chain leaf -> root: the fp64 recurrence value = reward + discount*value (agent.py:195) is replayed in
     // order; the lane that owns a path position keeps the value that reached it.
     const int top = len - 1;
@@ -568,7 +753,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             const int pos = gl + G * j;
             if (active && pos < len)
                 backup_slot(p, rec(p, tree, pf.slot[j] >> kPathShift), pf.slot[j] & (kMaxActions - 1), pf.c[j], pf.vs[j],
-                            vins[pos], (pos == top) ? rnew : pf.rw[j], pos == top, nb, mn_l, mx_l);
+                            vins[pos], (pos == top) ? rnew : pf.rw[j], pos == top, nb, hi0, mn_l, mx_l);
         }
     } else if (!__any(len > G)) {
         // every path of this wavefront fits one group: lane gl owns position gl, its slot came with the prefetch;
@@ -584,7 +769,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         }
         if (has)
             backup_slot(p, rec(p, tree, pf.slot[0] >> kPathShift), pf.slot[0] & (kMaxActions - 1), pf.c[0], pf.vs[0], vin,
-                        rw, gl == top, nb, mn_l, mx_l);
+                        rw, gl == top, nb, hi0, mn_l, mx_l);
     } else {
         // long paths: groups of G positions from the leaf down, lane j of a round owns position top-base-j
         for (int base = 0;; base += G) {
@@ -613,9 +798,10 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
                 if (gl == j) vin = v;
                 if (j < n_here) v = (double)rj + p.discount * v;
             }
-            if (has) backup_slot(p, r, k, c, vs, vin, rw, pos == top, nb, mn_l, mx_l);
+            if (has) backup_slot(p, r, k, c, vs, vin, rw, pos == top, nb, hi0, mn_l, mx_l);
         }
     }
+    MZ_TRACE(3);                                 // backup: chain replayed, slots updated
     if (active && gl == 0) {                          // the root (reward None -> chain ends, agent.py:195)
         const int rc = pf.root_count + 1;
         const double rvs = pf.root_vsum + v;
@@ -636,6 +822,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (mn_l < p.mm_min[tree]) p.mm_min[tree] = mn_l;
         }
     }
+    MZ_TRACE(4);                                 // backup: root and min/max updated
 }
 
 }  // namespace

@@ -127,6 +127,23 @@ class TreePool:
         _lib.check(fn(self._h, p, r, v, self._parent.data_ptr(), self._action.data_ptr()))
         return self._parent, self._action
 
+    def search_injected(self, policy, reward, value, noise=None, frac=0.25, legal=None, n_legal=None, logits=False,
+                        num_simulations=None, events=None):
+        """run_mcts (agent.py:198-211) against given network outputs, enqueued by one native call
+        (mz_search_move_injected): policy [N+1,T,A] f32 (row 0 = the root's masked policy), reward/value [N+1,T] f32.
+        events: optional ctypes array of 2*(N-1) hipEvent_t recorded around the fused steps (measurement)."""
+        self._sync_stream()
+        N = self.N if num_simulations is None else int(num_simulations)
+        p = _check_tensor('policy', policy, torch.float32, (N + 1, self.T, self.A), self.device)
+        r = _check_tensor('reward', reward, torch.float32, (N + 1, self.T), self.device)
+        v = _check_tensor('value', value, torch.float32, (N + 1, self.T), self.device)
+        nz = None if noise is None else _check_tensor('noise', noise, torch.float64, (self.T, self.A), self.device)
+        lg = None if legal is None else _check_tensor('legal', legal, torch.int32, (self.T, self.A), self.device)
+        nl = None if n_legal is None else _check_tensor('n_legal', n_legal, torch.int32, (self.T,), self.device)
+        _lib.check(self._lib.mz_search_move_injected(self._h, N, p, int(bool(logits)), r, v, lg, nl, nz, float(frac),
+                                                     self._parent.data_ptr(), self._action.data_ptr(), events))
+        return self._parent, self._action
+
     # ------------------------------------------------------------------ results
     def root_stats(self):
         """-> visits [T,A] i32, root_value [T] f64, minmax [T,2] f64, policy [T,A] f32 (agent.py:229-231)."""

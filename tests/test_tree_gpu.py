@@ -127,6 +127,54 @@ def test_logits_any_lanes_within_exp_tolerance(lanes, ad):
         pool.close()
 
 
+def _tied_priors(inp, mode, rng):
+    """Replaces the non-root priors of synthetic inputs by ones that make score ties (or irregular values) common."""
+    pri = inp['priors']
+    N1, T, A = pri.shape
+    if mode == 'equal':                 # every child of a node scores the same until visited: largest action wins
+        pri[1:] = np.float32(1.0 / A)
+    elif mode == 'levels':              # three distinct values: long runs of equal priors
+        lv = np.array([0.5, 0.25, 0.125], np.float32)
+        pri[1:] = lv[rng.integers(0, 3, size=(N1 - 1, T, A))] / A
+    elif mode == 'absorbed':            # a few real priors; the rest so small that prior * 2 log(n+1) vanishes in the sum
+        tiny = (10.0 ** rng.uniform(-38, -20, size=(N1 - 1, T, A))).astype(np.float32)
+        big = rng.random((N1 - 1, T, A)) < 2.0 / A
+        pri[1:] = np.where(big, rng.random((N1 - 1, T, A)).astype(np.float32) * 0.5, tiny)
+    elif mode == 'irregular':           # values the prefix argument does not cover: the node must be read whole
+        bad = rng.random((N1 - 1, T, A)) < 0.03
+        vals = np.array([np.inf, -0.25, -np.inf], np.float32)[rng.integers(0, 3, size=(N1 - 1, T, A))]
+        pri[1:] = np.where(bad, vals, pri[1:])
+    return inp
+
+
+@pytest.mark.parametrize('mode', ['equal', 'levels', 'absorbed', 'irregular'])
+@pytest.mark.parametrize('shape', [(60, 9, 30, 16), (60, 18, 50, 16), (60, 18, 50, 4), (12, 65, 60, 64), (12, 100, 80, 32)],
+                         ids=lambda x: 'T%d_A%d_N%d_G%d' % x)
+def test_prefix_select_with_tied_priors(shape, mode, ad):
+    """Nodes keep their children by descending prior and select reads a prefix (mz_tree_dev.h): ties at the end of the
+    prefix, priors that vanish in the score, and non-finite / negative priors must all end where a full scan ends."""
+    from oracle import c_oracle
+    T, A, N, lanes = shape
+    rng = np.random.Generator(np.random.PCG64(7 + A + len(mode)))
+    for bounds, default, players in (((-1.0, 1.0), 0.0, 2), (None, 0.25, 1)):
+        inp = _tied_priors(synthetic_inputs(T, A, N, seed=31 + A, reward_mode='tanh', legal_mode='ragged'), mode, rng)
+        kw = dict(num_trees=T, num_actions=A, max_simulations=N, num_players=players, discount=0.97,
+                  default_value=default, known_bounds=bounds)
+        opool = c_oracle.OraclePool(**kw)
+        want = run_synthetic_on_pool(opool, inp, NumpyAdapter, temperature=1.0)
+        pool = hip_pool(lanes_per_tree=lanes, **kw)
+        got = run_synthetic_on_pool(pool, inp, ad, fused=True, temperature=1.0)
+        assert_same_search(got, want)
+        for t in range(0, T, 7):
+            if inp['n_legal'][t] == 0:
+                continue
+            for e in range(0, N + 1, 5):
+                a, b = pool.read_block(t, e), opool.read_block(t, e)
+                for key in ('actions', 'count', 'value_sum', 'prior', 'child'):
+                    np.testing.assert_array_equal(a[key], b[key], err_msg=f'{mode} tree {t} block {e} {key}')
+        pool.close()
+
+
 def test_pool_is_reusable_across_moves(ad):
     """reset() + expand_roots() starts a fresh search in the same memory (agent.py:220-221: no tree reuse)."""
     from oracle import c_oracle
