@@ -72,8 +72,9 @@ class SyntheticTreeMove:
     dominant = 'step_kernel'
     bound = 'hbm'
 
-    def __init__(self, wl, device, seed, lanes=1):
+    def __init__(self, wl, device, seed, lanes=1, event_stride=5):
         from muzero_amd.tree_pool import TreePool
+        self.event_stride = event_stride
         assert wl['T'] % lanes == 0, 'lanes must divide the trees per GPU'
         self.wl, self.device, self.nl = wl, device, lanes
         Tl = wl['T'] // lanes
@@ -114,8 +115,8 @@ class SyntheticTreeMove:
             events = None
             if timed_events and i == 0 and N > 1:     # HIP events around lane 0's fused steps, on its stream
                 events = (ctypes.c_void_p * (2 * (N - 1)))()
-                for j in range(2 * (N - 1)):
-                    events[j] = self.hip_events.new()
+                for s in range(self.event_stride // 2, N - 1, self.event_stride):       # a sample of the steps
+                    events[2 * s], events[2 * s + 1] = self.hip_events.new(), self.hip_events.new()
                 self.event_sets.append(events)
             with torch.cuda.stream(l['stream']):
                 pool = l['pool']
@@ -133,7 +134,8 @@ class SyntheticTreeMove:
         ms = []
         for events in self.event_sets:
             for j in range(0, len(events), 2):
-                ms.append(self.hip_events.elapsed_ms(ctypes.c_void_p(events[j]), ctypes.c_void_p(events[j + 1])))
+                if events[j]:
+                    ms.append(self.hip_events.elapsed_ms(ctypes.c_void_p(events[j]), ctypes.c_void_p(events[j + 1])))
         return float(np.mean(ms)) * 1e-3 if ms else None
 
 
@@ -174,27 +176,30 @@ class HipEvents:
 
 
 class MoveEvents:
-    """HIP events per simulation, recorded by mz_search_move on the launch stream: [0] before the inference, [1] after
-    its dominant kernel (TicTacToe: the job kernel; CartPole: the whole inference), [2] after the tree step (TicTacToe:
-    head + tree step are one launch).  One set per sampled timed step."""
+    """HIP events for a sample of a move's simulations, recorded by mz_search_move on the launch stream: [0] before the
+    inference, [1] after its dominant kernel (TicTacToe: the job kernel; CartPole: the whole inference), [2] after the
+    tree step (TicTacToe: head + tree step are one launch).  A record costs ~13 us of stream time, so only every
+    `stride`-th simulation of a sampled step is timed."""
 
-    def __init__(self, num_simulations):
+    def __init__(self, num_simulations, stride):
         import ctypes
         self.ev, self.N, self.ct = HipEvents(), num_simulations, ctypes
+        self.sampled = list(range(stride // 2, num_simulations, stride)) or [0]
         self.sets = []
 
     def new_set(self):
         arr = (self.ct.c_void_p * (4 * self.N))()
-        for i in range(4 * self.N):
-            arr[i] = self.ev.new()
+        for s in self.sampled:
+            for j in range(3):
+                arr[4 * s + j] = self.ev.new()
         self.sets.append(arr)
         return arr
 
     def durations(self):
-        """-> (dominant kernel s, rest of the simulation s), each averaged over the sampled steps"""
+        """-> (dominant kernel s, rest of the simulation s), each averaged over the sampled simulations"""
         first, rest = [], []
         for arr in self.sets:
-            for s in range(self.N):
+            for s in self.sampled:
                 e0, em, e1 = (self.ct.c_void_p(arr[4 * s + j]) for j in range(3))
                 first.append(self.ev.elapsed_ms(e0, em))
                 rest.append(self.ev.elapsed_ms(em, e1))
@@ -207,7 +212,7 @@ class NetworkMove:
     reference path of MCTSAgent.make_move, batched."""
     bound = 'mfma'
 
-    def __init__(self, wl, device, seed, world, lanes=1):
+    def __init__(self, wl, device, seed, world, lanes=1, event_stride=5):
         from muzero_amd.games import cartpole, tictactoe
         from muzero_amd.selfplay import LockstepSearch, PipelinedSearch, TrajectoryGather
         mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[wl['net']]
@@ -242,7 +247,7 @@ class NetworkMove:
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
-        self.hooks = MoveEvents(wl['N'])
+        self.hooks = MoveEvents(wl['N'], event_stride)
         self.gather = TrajectoryGather(T, A, device) if world > 1 else None
 
     def run(self, timed_events=False):
@@ -268,10 +273,11 @@ def measured_traffic(workload, kernel):
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    for name, row in data.get('kernels', {}).items():
-        if name.startswith(kernel):
-            return row['traffic_bytes_per_launch'], os.path.basename(files[-1])
-    return None, None
+    rows = [row for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
+    if not rows:
+        return None, None
+    row = max(rows, key=lambda r: r['launches'])          # e.g. step_kernel<G, P, true> among its instantiations
+    return row['traffic_bytes_per_launch'], os.path.basename(files[-1])
 
 
 def cpu_baseline(wl, seconds):
@@ -333,6 +339,8 @@ def main():
                     help='split the games of a GPU into this many lockstep lanes on separate HIP streams')
     ap.add_argument('--event-every', type=int, default=4,
                     help='record the per-kernel HIP events on every K-th timed step (each record costs stream time)')
+    ap.add_argument('--event-stride', type=int, default=5,
+                    help='... and there on every S-th simulation only')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -352,8 +360,9 @@ def main():
         wl['T'] = args.trees
     with_net = wl['net'] is not None and not args.inject
     # per-rank seeds: every rank searches different games
-    move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes) if with_net
-            else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes))
+    stride = max(1, min(args.event_stride, wl['N'] // 4))
+    move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride) if with_net
+            else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
 
     for _ in range(args.warmup):
         move.run()
@@ -404,8 +413,12 @@ def main():
     else:
         avg = move.step_durations()
         achieved = tree_bytes_launch / avg / 1e9
+        traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
+                                else (None, None))
         roofline = {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_us': avg * 1e6,
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
+                    'avg_launch_us': avg * 1e6,
                     'bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d}
         # all lanes together: algorithmic bytes of every simulation of the timed region over its wall time
         extra = {'aggregate_algorithmic_GBps': sims_rank * bytes_per_simulation(wl['A'], mean_d, wl['A']) / elapsed / 1e9}

@@ -228,10 +228,11 @@ typedef struct mz_move_io {
     double* out_minmax;            /* [T, 2] f64 or NULL */
     float* out_policy;             /* [T, A] f32 or NULL */
     int32_t* out_action;           /* [T] i32 or NULL */
-    void** events;                 /* NULL, or HOST array of 4*N hipEvent_t recorded per simulation: [0] before the
-                                      inference, [1] between its two launches (if it has two), [2] and [3] after the
-                                      tree step -- which shares the second launch for the TicTacToe network, so
-                                      [1]..[2] spans head + tree step there (measurement only) */
+    void** events;                 /* NULL, or HOST array of 4*N hipEvent_t (measurement only); for every simulation s
+                                      whose events[4s] is not NULL: [4s] is recorded before the inference, [4s+1] between
+                                      its two launches (if it has two), [4s+2] after the tree step -- which shares the
+                                      second launch for the TicTacToe network, so [4s+1]..[4s+2] spans head + tree step
+                                      there; [4s+3] is unused.  A record costs ~13 us of stream time: sample sparsely */
 } mz_move_io_t;
 
 /* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in
@@ -246,7 +247,8 @@ int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
  *                                  (logits when is_logits != 0, see mz_expand_backprop_logits)
  *   reward, value [N+1, T] f32 device (row 0 unused); legal/n_legal as mz_expand_roots; noise as mz_add_root_noise
  *   parent_block, action [T] i32 device workspaces (the last select's outputs)
- *   events: NULL, or HOST array of 2*(N-1) hipEvent_t recorded before and after each fused step (measurement only) */
+ *   events: NULL, or HOST array of 2*(N-1) hipEvent_t; step s (1-based) with events[2(s-1)] != NULL is bracketed by
+ *           events[2(s-1)] and events[2(s-1)+1] (measurement only; sample sparsely, a record costs stream time) */
 int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations, const float* policy, int32_t is_logits,
                             const float* reward, const float* value, const int32_t* legal, const int32_t* n_legal,
                             const double* noise, double noise_frac, int32_t* parent_block, int32_t* action,

@@ -1110,6 +1110,218 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// Latency-oriented CartPole inference for small batches: 16 games per 512-thread workgroup on v_mfma_f32_16x16x4_f32.
+// The 32-row kernel above runs 64 dependent 64-cycle MFMAs per wavefront and stage (1024 games = 32 workgroups on 256
+// CUs, 25 us a call); here eight wavefronts own 16 output columns each and split K into two accumulator chains, so a
+// stage is 2 x 16 dependent 32-cycle MFMAs.  Same stages, same packed weights, same outputs.
+struct BFrag16 {
+    float2 v[16];
+};
+// W packed [16][128][8]: lane (n = 16*wave + lane%16, q = lane/16) takes k = 8*kb + 2*q, +1
+__device__ __forceinline__ void load_b16(BFrag16& b, const float* __restrict__ Wp, int lane, int wave) {
+    const float2* wp = reinterpret_cast<const float2*>(Wp) + (size_t)(wave * 16 + (lane & 15)) * 4 + (lane >> 4);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) b.v[kb] = wp[kb * 512];
+}
+// sA[16][128] (LDS, stride kLd) * W[128][this wave's 16 columns]; C/D layout: [i] = row 4*(lane/16) + i, column lane%16
+__device__ __forceinline__ f32x4 mma16(const float* sA, const BFrag16& b, int lane) {
+    const float* ap = sA + (lane & 15) * kLd + 2 * (lane >> 4);
+    float2 a[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) a[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // even / odd kb: two chains, added at the end
+#pragma unroll
+    for (int kb = 0; kb < 16; kb += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].x, b.v[kb].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1].x, b.v[kb + 1].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].y, b.v[kb].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1].y, b.v[kb + 1].y, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+// dot of a 128-float LDS row with 128 weights by the 16 threads of a row (q = 0..15 takes 8 floats each); all get the sum
+__device__ __forceinline__ float dot8x16(const float* h, const float* wv, int q) {
+    const float4 a0 = *reinterpret_cast<const float4*>(h + 8 * q), a1 = *reinterpret_cast<const float4*>(h + 8 * q + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(wv + 8 * q), b1 = *reinterpret_cast<const float4*>(wv + 8 * q + 4);
+    float s = a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+    s += __shfl_xor(s, 1, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 8, 16);
+    return s;
+}
+
+constexpr int kThreads16 = 512;
+constexpr int kCart16MaxBatch = 8192;      // up to two 16-game workgroups per CU; larger batches take the 32/64-row tiles
+
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B, const float* __restrict__ in_base,
+                                                                const int* __restrict__ parent_block, long block_stride,
+                                                                const int* __restrict__ action,
+                                                                float* __restrict__ out_hidden, float* __restrict__ out_reward,
+                                                                float* __restrict__ out_value, float* __restrict__ out_logits,
+                                                                float* __restrict__ out_value_raw) {
+    constexpr int ROWS = 16;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
+    __shared__ long sRowOff[ROWS];
+    __shared__ float sAct[ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, q4 = lane >> 4;
+    const int n = wave * 16 + n16;                       // this lane's output column
+    const int row0 = blockIdx.x * ROWS;
+    float* sX = sBuf[0];
+    float* sH = sBuf[1];
+    BFrag16 b0, b1;
+    load_b16(b0, INITIAL ? w.rep_dense_p : w.dyn_conv_p, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        float a = 0.f;
+        if (b < B) {
+            if (INITIAL) {
+                off = (long)b * 4;
+            } else {
+                const int pb = parent_block ? parent_block[b] : 0;
+                if (pb >= 0) off = (long)pb * block_stride + (long)b * 128;
+                a = action[b] == 1 ? 1.f : 0.f;
+            }
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    // stores relu(acc + bias (+ extra)) of this wave's 16 columns into an LDS tile
+    auto store = [&](const f32x4& acc, float bias, float* sOut, bool relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = acc[i] + bias;
+            sOut[(4 * q4 + i) * kLd + n] = relu ? fmaxf(v, 0.f) : v;
+        }
+    };
+    f32x4 acc;
+    if (INITIAL) {
+        // scalar_to_support two-hot (utils.py:138-143, network.py:107-116) -> Conv1D k=4 valid 101 -> 128 relu
+        // (games/cartpole.py:98): only <= 8 of the 404 inputs are non-zero, gathered on the VALU.
+        const int nn = tid & 127;
+        const float lo[4] = {-4.8f, -5.f, -0.418f, -5.f}, hi[4] = {4.8f, 5.f, 0.418f, 5.f};
+        const float bn = w.rep_conv_b[nn];
+        for (int r = tid >> 7; r < ROWS; r += 4) {
+            float s = bn;
+            if (sRowOff[r] >= 0) {
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const float x = (in_base[sRowOff[r] + pos] - lo[pos]) / (hi[pos] - lo[pos]);
+                    const float y = 100.f * (sqrtf(x + 1.f) - 1.f) / (sqrtf(2.f) - 1.f);
+                    const float fl = floorf(y);
+                    const float pf = y - fl;
+                    const int il = (int)fl, ih = (int)ceilf(y);
+                    // tf.one_hot yields an all-zero row for an out-of-range index
+                    if (ih >= 0 && ih <= 100) s += pf * w.rep_conv[(pos * 101 + ih) * 128 + nn];
+                    if (il >= 0 && il <= 100) s += (1.f - pf) * w.rep_conv[(pos * 101 + il) * 128 + nn];
+                }
+            }
+            sX[r * kLd + nn] = fmaxf(s, 0.f);
+        }
+        load_b16(b1, w.pred_dense1_p, lane, wave);
+        __syncthreads();
+        acc = mma16(sX, b0, lane);                                            // Dense relu = hidden (:101)
+    } else {
+        {   // gather leaf.parent.hidden_state rows (agent.py:204) into LDS: 16 rows x 32 float4
+            const int r = tid >> 5, c4 = tid & 31;
+            const long off = sRowOff[r];
+            const float4 v = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sH + r * kLd + c4 * 4) = v;
+        }
+        load_b16(b1, w.dyn_dense_p, lane, wave);
+        __syncthreads();
+        // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
+        acc = mma16(sH, b0, lane);
+        const float bn = w.dyn_conv_b[n], pn = w.dyn_plane[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q4 + i;
+            sX[row * kLd + n] = fmaxf(acc[i] + bn + sAct[row] * pn, 0.f);
+        }
+        load_b16(b0, w.dyn_rdense_p, lane, wave);
+        __syncthreads();
+        acc = mma16(sX, b1, lane);                                            // Dense relu = hidden' (:108)
+        load_b16(b1, w.pred_dense1_p, lane, wave);
+    }
+    {   // hidden state out (both modes); sH's previous contents (the gathered input) are no longer read
+        const float bn = (INITIAL ? w.rep_dense_b : w.dyn_dense_b)[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q4 + i;
+            const float v = fmaxf(acc[i] + bn, 0.f);
+            sH[row * kLd + n] = v;
+            if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 128 + n] = v;
+        }
+    }
+    __syncthreads();
+    const int row = (tid >> 4) & 15, q = tid & 15, b = row0 + row;        // 16 threads per row (threads 0..255)
+    const bool rowthread = tid < ROWS * 16;
+    const bool live = rowthread && sRowOff[row] >= 0;
+    if (!INITIAL) {
+        // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114)
+        acc = mma16(sH, b0, lane);
+        store(acc, w.dyn_rdense_b[n], sX, true);
+        __syncthreads();
+        if (rowthread) {
+            const float s = dot8x16(sX + row * kLd, w.dyn_reward_w, q);
+            if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        }
+        __syncthreads();
+    }
+    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124); b1 = pred_dense1 in both modes
+    load_b16(b0, w.pred_dense2_p, lane, wave);
+    acc = mma16(sH, b1, lane);
+    store(acc, w.pred_dense1_b[n], sX, true);
+    load_b16(b1, w.pred_value_p, lane, wave);
+    __syncthreads();
+    acc = mma16(sX, b0, lane);
+    __syncthreads();
+    store(acc, w.pred_dense2_b[n], sH, true);
+    __syncthreads();
+    // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
+    acc = mma16(sH, b1, lane);
+    store(acc, w.pred_value_b[n], sX, false);
+    __syncthreads();
+    if (rowthread) {
+        float* z = sX + row * kLd;
+        float mx = -INFINITY;
+        for (int j = q; j < 101; j += 16) mx = fmaxf(mx, z[j]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float den = 0.f;
+        for (int j = q; j < 101; j += 16) {
+            const float e = expf(z[j] - mx);
+            z[j] = e;
+            den += e;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) den += __shfl_xor(den, o, 16);
+        float y = 0.f;
+        for (int j = q; j < 101; j += 16) {
+            const float pj = z[j] / den;
+            if (out_value_raw && live) out_value_raw[(size_t)b * 101 + j] = pj;
+            y += pj * (float)j;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) y += __shfl_xor(y, o, 16);
+        if (q == 0 && live) {
+            y = y / 100.f;
+            const float t = (sqrtf(2.f) - 1.f) * y + 1.f;
+            out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
+        }
+        // policy logits: Dense 2 (:127)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float s = dot8x16(sH + row * kLd, w.pred_policy_w + o * 128, q);
+            if (q == 0 && live) out_logits[(size_t)b * 2 + o] = s + w.pred_policy_b[o];
+        }
+    }
+}
+
 struct Packer {
     std::vector<float> buf;
     size_t add(const float* src, size_t n) {
@@ -1491,6 +1703,10 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
         const int nhb = (batch + 15) / 16;
         ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
                                                           out_value, out_logits, out_value_raw);
+    } else if (batch <= kCart16MaxBatch) {
+        cartpole16_kernel<true><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
+                                                                         out_hidden, nullptr, out_value, out_logits,
+                                                                         out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<true, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
@@ -1545,6 +1761,10 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
         else
             ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
                                                                out_reward, out_value, out_logits, out_value_raw);
+    } else if (batch <= kCart16MaxBatch) {
+        cartpole16_kernel<false><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs,
+                                                                          action, out_hidden, out_reward, out_value,
+                                                                          out_logits, out_value_raw);
     } else {
         if (rows == 64)
             cartpole_kernel<false, 2><<<nrb, kThreads, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs, action,

@@ -26,14 +26,16 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
     MZ_TRY_(mz_add_root_noise(pool, io->noise, io->noise_frac));
     MZ_TRY_(mz_select(pool, io->parent_block, io->action));
     for (int s = 0; s < N; ++s) {
-        if (ev) {
+        const bool timed = ev && ev[4 * s];           // a simulation whose events are NULL is not timed
+        if (timed) {
             MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s]), static_cast<hipStream_t>(io->stream)));
             MZ_TRY_(mz_net_set_mid_event(net, ev[4 * s + 1]));
+        } else if (ev) {
+            MZ_TRY_(mz_net_set_mid_event(net, nullptr));
         }
         MZ_TRY_(mz_infer_recurrent_step(net, pool, s + 1 < N, io->hidden, io->parent_block, (int64_t)T * H, io->action,
                                         io->hidden + (size_t)(s + 1) * T * H, io->reward, io->value, io->logits));
-        if (ev) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
-        if (ev) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 3]), static_cast<hipStream_t>(io->stream)));
+        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
     MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
@@ -67,10 +69,11 @@ extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations,
             MZ_TRY_(is_logits ? mz_expand_backprop_logits(pool, pol, rw, vl) : mz_expand_backprop(pool, pol, rw, vl));
             break;
         }
-        if (events) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1)]), pool->stream));
+        const bool timed = events && events[2 * (s - 1)];      // a step whose events are NULL is not timed
+        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1)]), pool->stream));
         MZ_TRY_(is_logits ? mz_step_logits(pool, pol, rw, vl, parent_block, action)
                           : mz_step(pool, pol, rw, vl, parent_block, action));
-        if (events) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1) + 1]), pool->stream));
+        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1) + 1]), pool->stream));
     }
 #undef MZ_TRY_
     return MZ_OK;

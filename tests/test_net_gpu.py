@@ -70,6 +70,27 @@ def test_initial_and_recurrent_inference(kind, B):
     assert outs[B - 1].value == float(out2.batch_value_scalar[B - 1])
 
 
+def test_cartpole_large_batch_takes_the_row_tile_kernel():
+    """Batches up to 8192 games run 16 per workgroup (cartpole16_kernel); beyond that the 32/64-row tiles do."""
+    net, ref = make('cartpole')
+    B = 8300
+    rng = np.random.default_rng(5)
+    obs = observations('cartpole', B, rng)
+    out = net.initial_inference(obs)
+    h, v, logits, raw = ref.initial_inference(obs)
+    close(out.batch_hidden_state, h)
+    close(out.batch_value_scalar, v, 100.0)
+    close(out.batch_policy_logits, logits)
+    action = rng.integers(0, 2, size=B)
+    out2 = net.recurrent_inference(out.batch_hidden_state, action)
+    h2, r2, v2, l2, raw2 = ref.recurrent_inference(h, action)
+    close(out2.batch_hidden_state, h2)
+    close(out2.batch_reward_scalar, r2)
+    close(out2.batch_value_scalar, v2, 100.0)
+    close(out2.batch_policy_logits, l2)
+    close(out2.batch_value, raw2)
+
+
 @pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
 def test_pool_gather_path_and_inactive_rows(kind):
     """recurrent_inference reading leaf.parent.hidden_state rows by parent block from the [N+1][T][H] tensor and

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Assemble profiles/*_hbm_traffic_<workload>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python tools/pmc_to_json.py <workload> <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>"
+
+Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): both counters are KiB; FETCH_SIZE counts wide
+coalesced reads at half their bytes, so fetch bytes = 2 * FETCH_SIZE * 1024.
+"""
+import collections, csv, json, re, sys
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '')
+    name = re.sub(r'^void ', '', name)
+    return name.split('(')[0]
+
+def mean_per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter and 'at::' not in r['Kernel_Name'] and '__amd' not in r['Kernel_Name']:
+            agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+def main():
+    workload, fetch_csv, write_csv, out, command = sys.argv[1:6]
+    f, w = mean_per_kernel(fetch_csv, 'FETCH_SIZE'), mean_per_kernel(write_csv, 'WRITE_SIZE')
+    kernels = {}
+    for k in sorted(f):
+        if k not in w:
+            continue
+        fb, wb = 2 * f[k][0] * 1024, w[k][0] * 1024
+        kernels[k] = {'launches': f[k][1], 'FETCH_SIZE_KiB': f[k][0], 'WRITE_SIZE_KiB': w[k][0],
+                      'fetch_bytes_corrected': fb, 'write_bytes': wb, 'traffic_bytes_per_launch': fb + wb}
+    json.dump({'workload': workload, 'round': 1, 'command': command,
+               'unit_note': 'rocprofv3 FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE counts wide coalesced reads at half '
+                            'their bytes (MI355X_MICROARCH.md, HBM): fetch bytes = 2 * FETCH_SIZE * 1024',
+               'kernels': kernels}, open(out, 'w'), indent=1)
+    for k, v in kernels.items():
+        print('%-40s %8.2f MB per launch (n=%d)' % (k[:40], v['traffic_bytes_per_launch'] / 1e6, v['launches']))
+
+main()
