@@ -145,6 +145,9 @@ struct TttDev {
     const float* pred_policy_b; // [9]
     const float* pred_head_p;   // packed [16][128][8]: column 0 = value head, 1..9 = policy heads, others zero
     const float* pred_head_b;   // [16]: value bias, 9 policy biases, zeros
+    const float* dyn_conv_h;    // the three GEMM operands of the job kernel again, as split-f16 fragments (pack_split_f16)
+    const float* dyn_dense_h;
+    const float* pred_conv_h;
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     float dyn_reward_b, pred_value_b;
@@ -570,6 +573,238 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
         tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
                 (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         tr[3] = job;
+    }
+}
+
+// ---- the same job kernel on split-f16 MFMA ---------------------------------------------------------------------------
+// An f32 value v is carried as two halfs, h = f16(v) and l = f16((v - h) * 2048): v = h + l/2048 to 22 mantissa bits.
+// A product a*b is then ah*bh + (ah*bl + al*bh)/2048 (+ al*bl/2^22, dropped: 2.4e-7 relative), every term an exact
+// f16 x f16 product accumulated in f32 by v_mfma_f32_32x32x16_f16.  Three of those cover 16 k's in 3 x 32 cycles; the
+// f32 MFMA takes 8 x 64 for the same 16 k's.  Measured against the fp64 oracle the outputs differ by ~1e-7, inside
+// the 1e-5 the f32 kernel is held to (tests/test_net_gpu.py) and no worse than f32 accumulation itself.
+// Operand images: weights pre-split on the host (Packer::add_split_f16, same bytes and the same register ring as the
+// f32 fragments); activation tiles in LDS as [row][128 h | 128 l] halfs on the f32 tile's 528-byte row stride, so the
+// fragment reads keep the f32 kernel's conflict-free geometry.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr int kLdH = 2 * kLd;        // tile row stride in halfs
+constexpr float kSplit = 2048.f, kUnsplit = 1.f / 2048.f;
+
+__device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
+    h = (_Float16)v;
+    l = (_Float16)((v - (float)h) * kSplit);
+}
+__device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
+    _Float16 h, l;
+    split_f16(v, h, l);
+    tile[row * kLdH + n] = h;
+    tile[row * kLdH + 128 + n] = l;
+}
+__device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
+    return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
+}
+
+// One 16-k block of a stage: acc += ah*bh, acc2 += ah*bl + al*bh.  The block's two weight registers are re-loaded with
+// the NEXT stage's fragments right after (in-place ring), the activation fragments are read two blocks ahead, and the
+// next tile's gather rides on the first four blocks.
+template <int T>
+__device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][2], BFrag& b, f32x16& acc, f32x16& acc2,
+                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
+                                            float4 (&stg)[4]) {
+    if (T + 2 < 8) {
+        af[(T + 2) % 3][0] = *reinterpret_cast<const float4*>(ap + (T + 2) * 16);
+        af[(T + 2) % 3][1] = *reinterpret_cast<const float4*>(ap + 128 + (T + 2) * 16);
+    }
+    const f16x8 ah = __builtin_bit_cast(f16x8, af[T % 3][0]), al = __builtin_bit_cast(f16x8, af[T % 3][1]);
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * T]), bl = __builtin_bit_cast(f16x8, b.v[2 * T + 1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+    b.v[2 * T] = wnext[(2 * T) * 256];
+    b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
+    if (T < 4) stg[T] = *reinterpret_cast<const float4*>(sptr[T] + src);
+    // pin the interleave: this block's LDS fragment reads, its three MFMAs, then its VMEM reads
+    if (T + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, T < 4 ? 3 : 2, 0);
+}
+
+template <int... T>
+__device__ __forceinline__ void mma_blocks_h(std::integer_sequence<int, T...>, const _Float16* ap, float4 (&af)[3][2],
+                                             BFrag& b, f32x16& acc, f32x16& acc2, const float4* __restrict__ wnext,
+                                             const float* const (&sptr)[4], int src, float4 (&stg)[4]) {
+    (mma_block_h<T>(ap, af, b, acc, acc2, wnext, sptr, src, stg), ...);
+}
+
+// acc += sA[32][128] * W (both split); returns with the cross terms folded in.
+__device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16& acc, int lane,
+                                           const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
+                                           float4 (&stg)[4]) {
+    const _Float16* ap = sA + (lane & 31) * kLdH + 8 * (lane >> 5);
+    float4 af[3][2];
+    af[0][0] = *reinterpret_cast<const float4*>(ap);
+    af[0][1] = *reinterpret_cast<const float4*>(ap + 128);
+    af[1][0] = *reinterpret_cast<const float4*>(ap + 16);
+    af[1][1] = *reinterpret_cast<const float4*>(ap + 128 + 16);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the ring-priming reads come first
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    mma_blocks_h(std::make_integer_sequence<int, 8>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
+}
+
+// Same jobs, stages, grid and outputs as ttt_job_kernel.
+__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B, const float* __restrict__ in_base,
+                                                                const int* __restrict__ parent_block, long block_stride,
+                                                                const int* __restrict__ action,
+                                                                float* __restrict__ out_hidden, float* __restrict__ ppart,
+                                                                float* __restrict__ rpart) {
+    constexpr int ROWS = 32;
+    __shared__ __attribute__((aligned(16))) float sTileF[2][ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sXF[ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
+    __shared__ long sRowOff[ROWS];
+    __shared__ int sAct[ROWS];
+    __shared__ int4 sDesc[24];
+    auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
+    _Float16* sX = reinterpret_cast<_Float16*>(sXF);
+    _Float16* sH = reinterpret_cast<_Float16*>(sHF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
+    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
+    const int n = wave * 32 + (lane & 31);
+    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_h) + n * 2 + (lane >> 5);   // + weights offset / 4
+
+    BFrag bw;
+    const int4 D0 = w.job_desc[dbase];
+    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
+    load_b(bw, w.dyn_conv_h + (size_t)D0.z * 16384, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            const int pb = parent_block ? parent_block[b] : 0;
+            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
+            a = action[b];
+            if (a < 0 || a > 8) a = 0;
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    const float* sptr[4];
+    unsigned svalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+        const long off = sRowOff[r];
+        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
+        if (off >= 0) svalid |= 1u << i;
+    }
+    float4 stg[4];
+    // gathered f32 rows -> split tile: 4 h halfs and 4 l halfs per thread and i, one 8-byte store each
+    auto commit = [&](_Float16* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+            const bool ok = (svalid >> i) & 1u;
+            const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
+            f16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 hj, lj;
+                split_f16(v[j], hj, lj);
+                h[j] = hj;
+                l[j] = lj;
+            }
+            *reinterpret_cast<f16x4*>(buf + r * kLdH + c4 * 4) = h;
+            *reinterpret_cast<f16x4*>(buf + r * kLdH + 128 + c4 * 4) = l;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
+    commit(tile(0));
+    __syncthreads();
+
+    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+    int buf = 0;
+#pragma unroll 1
+    for (int d = 0; d < d1; ++d) {
+        const int4 Dc = sDesc[d];
+        const bool has_next = d + 1 < d1;
+        const int4 Dn = sDesc[has_next ? d + 1 : d];
+        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
+        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
+        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
+        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
+        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
+        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
+        const float* wn = nkind == 0 ? w.dyn_conv_h + (size_t)ntap * 16384
+                        : nkind == 1 ? w.dyn_dense_h : w.pred_conv_h + (size_t)ncell * 16384;
+        const bool gather = has_next && nkind == 0;
+        const _Float16* sA = kind == 0 ? tile(buf) : kind == 1 ? sX : sH;
+        if (kind == 1 || first_tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        float ab[16];
+        if (kind == 0 && last_tap) {
+            // last tap of a cell: conv bias + action-plane bias of each accumulator row, requested under the MFMAs
+            // (action planes of the one-hot encoder are constant per cell: network.py:14-40)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
+        }
+        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+        mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        if (kind == 2) accp = acc;
+        if (kind == 0) {
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) store_split(sX, acc_row(0, r, lane), n, fmaxf(acc[r] + ab[r], 0.f));
+            }
+            if (gather) commit(tile(buf ^ 1));
+            __syncthreads();
+            if (gather) buf ^= 1;
+        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            const float bn = w.dyn_dense_b[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(0, r, lane);
+                const float v = fmaxf(acc[r] + bn, 0.f);
+                store_split(sH, row, n, v);
+                if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;   // f32, unsplit
+            }
+            __syncthreads();
+            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
+                const int row = tid >> 2, q = tid & 3;
+                float sdot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) sdot += load_split(sH, row, q * 32 + j) * w.dyn_reward_w[cell * 128 + q * 32 + j];
+                sdot += __shfl_xor(sdot, 1, 4);
+                sdot += __shfl_xor(sdot, 2, 4);
+                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
+            }
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
+            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(0, r, lane);
+                    if (sRowOff[row] >= 0) ppart[(size_t)(row0 + row) * 1152 + job * 128 + n] = accp[r];
+                }
+            }
+            if (gather) commit(tile(buf ^ 1));
+            __syncthreads();
+            if (gather) buf ^= 1;
+        }
     }
 }
 
@@ -1338,6 +1573,24 @@ struct Packer {
             for (int n = 0; n < N; ++n) p[((size_t)(k / 8) * 128 + n) * 8 + (k % 8)] = W[(size_t)k * ldw + n];
         return add(p);
     }
+    // W[128][128] row-major -> split-f16 MFMA fragments for v_mfma_f32_32x32x16_f16, the size of the f32 matrix:
+    // 16-byte entry [j = 2t + plane][n][g] holds the 8 halfs k = 16t + 8g .. +7 of column n; plane 0 = h = f16(w),
+    // plane 1 = l = f16((w - h) * 2048).  w ~= h + l/2048 to 22 mantissa bits.
+    size_t add_split_f16(const float* W, int ldw) {
+        std::vector<_Float16> p((size_t)128 * 128 * 2);
+        for (int k = 0; k < 128; ++k)
+            for (int n = 0; n < 128; ++n) {
+                const float w = W[(size_t)k * ldw + n];
+                const _Float16 h = (_Float16)w;
+                const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+                const int t = k / 16, g = (k % 16) / 8, i = k % 8;
+                p[(((size_t)(2 * t) * 128 + n) * 2 + g) * 8 + i] = h;
+                p[(((size_t)(2 * t + 1) * 128 + n) * 2 + g) * 8 + i] = l;
+            }
+        std::vector<float> f((size_t)128 * 128);
+        memcpy(f.data(), p.data(), f.size() * sizeof(float));
+        return add(f);
+    }
 };
 
 constexpr int64_t kTttWeights = 3456 + 128 + 16384 + 128 + 157824 + 128 + 16384 + 128 + 1152 + 1 + 147456 + 128 + 16384 + 128 + 128 + 1 + 1152 + 9;
@@ -1374,6 +1627,12 @@ int ensure_scratch(mz_net* net, int batch) {
     MZ_HIP(hipMalloc(reinterpret_cast<void**>(&net->rpart), (size_t)cap * 9 * sizeof(float)));
     net->scratch_cap = cap;
     return MZ_OK;
+}
+
+// MZ_JOB_F32=1: the f32-MFMA job kernel instead of the split-f16 one (comparison runs)
+bool job_f32() {
+    static const bool v = getenv("MZ_JOB_F32") != nullptr;
+    return v;
 }
 
 int launch_status(const char* what) {
@@ -1518,6 +1777,17 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         off.push_back(pk.add(desc));                                   // 16
         off.push_back(pk.add_packed(headW.data(), 128, 16, 16));       // 17
         off.push_back(pk.add(headB));                                  // 18
+        for (int t = 0; t < 9; ++t) {
+            const size_t o = pk.add_split_f16(dyn_conv + (size_t)t * 137 * 128, 128);
+            if (t == 0) first = o;
+        }
+        off.push_back(first);                                          // 19
+        off.push_back(pk.add_split_f16(dyn_dense, 128));               // 20
+        for (int c = 0; c < 9; ++c) {
+            const size_t o = pk.add_split_f16(pred_conv + (size_t)c * 128 * 128, 128);
+            if (c == 0) first = o;
+        }
+        off.push_back(first);                                          // 21
     } else {
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
@@ -1602,6 +1872,9 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         t.job_desc = reinterpret_cast<const int4*>(d + off[16]);
         t.pred_head_p = d + off[17];
         t.pred_head_b = d + off[18];
+        t.dyn_conv_h = d + off[19];
+        t.dyn_dense_h = d + off[20];
+        t.pred_conv_h = d + off[21];
     } else {
         CartDev& c = net->cart;
         c.rep_conv = d + off[0];
@@ -1741,10 +2014,14 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
             if (net->trace)
                 ttt_job_kernel_traced<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(
                     net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart, net->trace);
-            else
+            else if (job_f32())
                 ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
                                                                             action, out_hidden, net->ppart, net->rpart,
                                                                             nullptr);
+            else
+                ttt_job_kernel_h<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                              bs, action, out_hidden, net->ppart,
+                                                                              net->rpart);
         } else if (rows == 64)
             ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
                                                                    out_hidden, net->ppart, net->rpart, cell_order(),
@@ -1803,9 +2080,14 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     if (s != MZ_OK) return s;
     hipStream_t st = net->stream;
     const int nrb32 = (batch + 31) / 32;
-    ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                (long)block_stride, action, out_hidden, net->ppart,
-                                                                net->rpart, nullptr);
+    if (job_f32())
+        ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                    (long)block_stride, action, out_hidden, net->ppart,
+                                                                    net->rpart, nullptr);
+    else
+        ttt_job_kernel_h<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                      (long)block_stride, action, out_hidden, net->ppart,
+                                                                      net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)
