@@ -585,6 +585,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
 // Operand images: weights pre-split on the host (Packer::add_split_f16, same bytes and the same register ring as the
 // f32 fragments); activation tiles in LDS as [row][128 h | 128 l] halfs on the f32 tile's 528-byte row stride, so the
 // fragment reads keep the f32 kernel's conflict-free geometry.
+#ifndef MZ_EXP_H
+#define MZ_EXP_H 0
+#endif
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int kLdH = 2 * kLd;        // tile row stride in halfs
@@ -594,11 +597,19 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
     h = (_Float16)v;
     l = (_Float16)((v - (float)h) * kSplit);
 }
+// Writes element (row, n) of a split tile.  Called by all 64 lanes with n = (a multiple of 32) + lane % 32 and a row that
+// depends on lane / 32 only: lanes n and n^1 trade their (h, l) pairs, the even one writes both h's, the odd one both
+// l's -- one 4-byte LDS write per lane instead of two 2-byte ones.
 __device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
     _Float16 h, l;
     split_f16(v, h, l);
-    tile[row * kLdH + n] = h;
-    tile[row * kLdH + 128 + n] = l;
+#if MZ_EXP_H != 1
+    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+    const bool odd = n & 1;
+    const unsigned word = odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
+    *reinterpret_cast<unsigned*>(tile + row * kLdH + (odd ? 128 + n - 1 : n)) = word;
+#endif
 }
 __device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
     return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
@@ -620,9 +631,13 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+#if MZ_EXP_H != 2
     b.v[2 * T] = wnext[(2 * T) * 256];
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
+#endif
+#if MZ_EXP_H != 3
     if (T < 4) stg[T] = *reinterpret_cast<const float4*>(sptr[T] + src);
+#endif
     // pin the interleave: this block's LDS fragment reads, its three MFMAs, then its VMEM reads
     if (T + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -716,14 +731,16 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
             const bool ok = (svalid >> i) & 1u;
             const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
+            // h by the packed round-toward-zero conversion (v - h is exact whatever the rounding of h; the residual is
+            // then < 1 ulp of h instead of half of one, still 21 bits in all), l likewise
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+            const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+            const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+            const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * kSplit, (v[1] - (float)h01[1]) * kSplit));
+            const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * kSplit, (v[3] - (float)h23[1]) * kSplit));
             f16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                _Float16 hj, lj;
-                split_f16(v[j], hj, lj);
-                h[j] = hj;
-                l[j] = lj;
-            }
+            h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
+            l[0] = l01[0]; l[1] = l01[1]; l[2] = l23[0]; l[3] = l23[1];
             *reinterpret_cast<f16x4*>(buf + r * kLdH + c4 * 4) = h;
             *reinterpret_cast<f16x4*>(buf + r * kLdH + 128 + c4 * 4) = l;
         }
@@ -737,16 +754,18 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll
     for (int r = 0; r < 16; ++r) accp[r] = 0.f;
     int buf = 0;
+    MZ_TRACE_DECL;
+    MZ_TRACE_NW(0);                                  // prologue
 #pragma unroll 1
     for (int d = 0; d < d1; ++d) {
         const int4 Dc = sDesc[d];
         const bool has_next = d + 1 < d1;
         const int4 Dn = sDesc[has_next ? d + 1 : d];
+        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
         const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
         const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
         const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
         const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
-        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
         const float* wn = nkind == 0 ? w.dyn_conv_h + (size_t)ntap * 16384
                         : nkind == 1 ? w.dyn_dense_h : w.pred_conv_h + (size_t)ncell * 16384;
@@ -756,23 +775,27 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
-        float ab[16];
-        if (kind == 0 && last_tap) {
-            // last tap of a cell: conv bias + action-plane bias of each accumulator row, requested under the MFMAs
-            // (action planes of the one-hot encoder are constant per cell: network.py:14-40)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
-        }
         if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+        MZ_TRACE_NW(1);                              // stage set-up
         mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        MZ_TRACE_NW(2);                              // MFMA section
         if (kind == 2) accp = acc;
         if (kind == 0) {
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+            if (last_tap) {       // last tap: + conv bias + action-plane bias (the one-hot encoder's planes are
+                                  // constant per cell: network.py:14-40), relu -> sX (games/tictactoe.py:189)
+                float ab[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) store_split(sX, acc_row(0, r, lane), n, fmaxf(acc[r] + ab[r], 0.f));
             }
+#if MZ_EXP_H != 3
+            MZ_TRACE_NW(6);                          // epilogue before the gather is committed
             if (gather) commit(tile(buf ^ 1));
+#endif
+            MZ_TRACE_NW(3);                          // epilogue
             __syncthreads();
+            MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             const float bn = w.dyn_dense_b[n];
@@ -783,7 +806,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 store_split(sH, row, n, v);
                 if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;   // f32, unsplit
             }
+            MZ_TRACE_NW(3);
             __syncthreads();
+            MZ_TRACE_NW(4);
             if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
                 const int row = tid >> 2, q = tid & 3;
                 float sdot = 0.f;
@@ -801,10 +826,14 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                     if (sRowOff[row] >= 0) ppart[(size_t)(row0 + row) * 1152 + job * 128 + n] = accp[r];
                 }
             }
+            MZ_TRACE_NW(6);                          // epilogue before the gather is committed
             if (gather) commit(tile(buf ^ 1));
+            MZ_TRACE_NW(3);
             __syncthreads();
+            MZ_TRACE_NW(4);
             if (gather) buf ^= 1;
         }
+        MZ_TRACE_NW(5);                              // after the barrier (reward dot)
     }
 }
 
@@ -1920,6 +1949,19 @@ int mz_net_set_stream(mz_net_t* net, void* stream) {
 }
 
 int64_t mz_net_training_steps(mz_net_t* net) { return net ? net->training_steps : -1; }
+
+#ifdef MZ_TREE_TRACE
+// experiment builds only: the per-wavefront phase counters of THIS translation unit (the job kernel's stamps)
+int mz_debug_net_trace(uint32_t* out, int64_t out_bytes) {
+    MZ_HIP(hipDeviceSynchronize());
+    MZ_REQUIRE(out_bytes == (int64_t)sizeof(unsigned) * kTraceWaves * 2 * kTracePhases, "trace buffer size");
+    MZ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_trace), (size_t)out_bytes));
+    void* sym = nullptr;
+    MZ_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tree_trace)));
+    MZ_HIP(hipMemset(sym, 0, (size_t)out_bytes));
+    return MZ_OK;
+}
+#endif
 
 /* Diagnostic, not part of include/mzhip.h: device buffer of 3 int64 per workgroup of the next cell-kernel launches. */
 int mzdbg_net_set_trace(mz_net_t* net, long long* device_buf) {

@@ -158,6 +158,16 @@ struct TreeTrace {
             }
         t = clock64();
     }
+    __device__ __forceinline__ void stamp_nowait(int phase) {       // without draining memory operations
+        const long long now = clock64();
+#pragma unroll
+        for (int i = 0; i < kTracePhases; ++i)
+            if (i == phase) {
+                clk[i] += (unsigned)(now - t);
+                cnt[i] += 1;
+            }
+        t = now;
+    }
     __device__ ~TreeTrace() {
         const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
         if ((threadIdx.x & 63) == 0 && wave < kTraceWaves)
@@ -170,7 +180,9 @@ struct TreeTrace {
 };
 #define MZ_TRACE_DECL TreeTrace mz_trace_
 #define MZ_TRACE(phase) mz_trace_.stamp(phase)
+#define MZ_TRACE_NW(phase) mz_trace_.stamp_nowait(phase)
 #else
+#define MZ_TRACE_NW(phase)
 #define MZ_TRACE_DECL
 #define MZ_TRACE(phase)
 #endif

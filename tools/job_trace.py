@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Profiling aid: where a wavefront of the TicTacToe job kernel spends its clocks (experiment build with -DMZ_TREE_TRACE).
+    MZ_LIB=tools/micro/libmzhip_trace.so python tools/job_trace.py"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from muzero_amd import _lib
+NAMES = ['prologue', 'stage set-up', 'MFMA section', 'commit / stores', 'barrier', 'after barrier', 'epilogue math']
+wl = dict(bench.WORKLOADS['tictactoe_4096x25'])
+dev = torch.device('cuda', 0)
+move = bench.NetworkMove(wl, dev, 1234, 1)
+lib = _lib.load()
+W, PH = 1 << 15, 12
+out = np.zeros((W, 2 * PH), np.uint32)
+read = lambda: lib.mz_debug_net_trace(ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(out.nbytes))
+move.run(); torch.cuda.synchronize(); read()
+move.run(); torch.cuda.synchronize(); read()
+launches = wl['N']
+used = out[:, PH] > 0
+clk, cnt = out[used, :PH].astype(np.float64) / launches, out[used, PH:].astype(np.float64) / launches
+print(int(used.sum()), 'wavefronts; shader clocks per wavefront and launch')
+for i, nm in enumerate(NAMES):
+    print(f'  {nm:14s} mean {clk[:, i].mean():8.0f}  max {clk[:, i].max():8.0f}   x{cnt[:, i].mean():5.1f}  -> {clk[:, i].sum() / max(cnt[:, i].sum(), 1):7.0f} each')
+print('  total          mean %8.0f  max %8.0f' % (clk.sum(1).mean(), clk.sum(1).max()))
