@@ -636,12 +636,15 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
 #endif
 #if MZ_EXP_H != 3
-    if (T < 4) stg[T] = *reinterpret_cast<const float4*>(sptr[T] + src);
+    if (T >= 6) {                                   // the tile two stages ahead, requested once stg has been committed
+        stg[2 * (T - 6)] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6)] + src);
+        stg[2 * (T - 6) + 1] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6) + 1] + src);
+    }
 #endif
     // pin the interleave: this block's LDS fragment reads, its three MFMAs, then its VMEM reads
     if (T + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, T < 4 ? 3 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, T >= 6 ? 4 : 2, 0);
 }
 
 template <int... T>
@@ -651,10 +654,12 @@ __device__ __forceinline__ void mma_blocks_h(std::integer_sequence<int, T...>, c
     (mma_block_h<T>(ap, af, b, acc, acc2, wnext, sptr, src, stg), ...);
 }
 
-// acc += sA[32][128] * W (both split); returns with the cross terms folded in.
+// acc += sA[32][128] * W (both split); returns with the cross terms folded in.  `mid` runs between the fourth and the
+// fifth block: the caller commits the tile gathered during the previous stage there, under this stage's MFMAs.
+template <typename Mid>
 __device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16& acc, int lane,
                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
-                                           float4 (&stg)[4]) {
+                                           float4 (&stg)[4], Mid&& mid) {
     const _Float16* ap = sA + (lane & 31) * kLdH + 8 * (lane >> 5);
     float4 af[3][2];
     af[0][0] = *reinterpret_cast<const float4*>(ap);
@@ -665,7 +670,9 @@ __device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16&
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    mma_blocks_h(std::make_integer_sequence<int, 8>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
+    mma_blocks_h(std::integer_sequence<int, 0, 1, 2, 3>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
+    mid();
+    mma_blocks_h(std::integer_sequence<int, 4, 5, 6, 7>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
 }
@@ -748,6 +755,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll
     for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
     commit(tile(0));
+    {   // stage 1's tile, if it gathers one, is on its way while stage 0 starts
+        const int4 D1 = w.job_desc[dbase + (d1 > 1 ? 1 : 0)];
+        const int src1 = (d1 > 1 && (D1.x & 7) == 0) ? D1.w * 128 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src1);
+    }
     __syncthreads();
 
     f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
@@ -761,7 +774,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         const int4 Dc = sDesc[d];
         const bool has_next = d + 1 < d1;
         const int4 Dn = sDesc[has_next ? d + 1 : d];
-        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
+        const int4 Dn2 = sDesc[d + 2 < d1 ? d + 2 : d];
+        const bool gather2 = d + 2 < d1 && __builtin_amdgcn_readfirstlane(Dn2.x & 7) == 0;
+        const int nsrc2 = __builtin_amdgcn_readfirstlane(Dn2.w);
         const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
         const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
         const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
@@ -777,7 +792,11 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         }
         if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
         MZ_TRACE_NW(1);                              // stage set-up
-        mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather ? nsrc * 128 : 0, stg);
+        // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
+        // stage's MFMAs; the tile after it is requested at the end of this stage
+        mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather2 ? nsrc2 * 128 : 0, stg, [&] {
+            if (gather) commit(tile(buf ^ 1));
+        });
         MZ_TRACE_NW(2);                              // MFMA section
         if (kind == 2) accp = acc;
         if (kind == 0) {
@@ -789,10 +808,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) store_split(sX, acc_row(0, r, lane), n, fmaxf(acc[r] + ab[r], 0.f));
             }
-#if MZ_EXP_H != 3
-            MZ_TRACE_NW(6);                          // epilogue before the gather is committed
-            if (gather) commit(tile(buf ^ 1));
-#endif
+            MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);                          // epilogue
             __syncthreads();
             MZ_TRACE_NW(4);                          // barrier
@@ -826,8 +842,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                     if (sRowOff[row] >= 0) ppart[(size_t)(row0 + row) * 1152 + job * 128 + n] = accp[r];
                 }
             }
-            MZ_TRACE_NW(6);                          // epilogue before the gather is committed
-            if (gather) commit(tile(buf ^ 1));
+            MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);
             __syncthreads();
             MZ_TRACE_NW(4);
