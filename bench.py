@@ -243,7 +243,7 @@ class NetworkMove:
         else:
             span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
             self.obs = ((torch.rand(T, 4, generator=g, device=device) * 2 - 1) * span).contiguous()
-            self.dominant = 'cartpole_kernel<recurrent>'
+            self.dominant = 'cartpole16_kernel<false>' if T <= 8192 else 'cartpole_kernel<false'
             self.flops_per_eval = 223232
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
