@@ -1171,7 +1171,9 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     const int tree = row0 + tid / G, gl = tid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
+    MZ_TRACE_DECL;
     ttt_head16<4, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
+    MZ_TRACE(0);                                                              // head
     if (active && gl < 11) {                                         // the plain outputs of mz_infer_recurrent
         const float x = sOut[tid / G][gl];
         if (gl < 9) out_logits[(size_t)tree * 9 + gl] = x;

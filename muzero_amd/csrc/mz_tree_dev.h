@@ -180,7 +180,11 @@ struct TreeTrace {
 };
 #define MZ_TRACE_DECL TreeTrace mz_trace_
 #define MZ_TRACE(phase) mz_trace_.stamp(phase)
+#ifdef MZ_JOB_TRACE
 #define MZ_TRACE_NW(phase) mz_trace_.stamp_nowait(phase)
+#else
+#define MZ_TRACE_NW(phase)
+#endif
 #else
 #define MZ_TRACE_NW(phase)
 #define MZ_TRACE_DECL

@@ -7,7 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from muzero_amd import _lib
-NAMES = ['prologue', 'stage set-up', 'MFMA section', 'commit / stores', 'barrier', 'after barrier', 'epilogue math']
+TREE = os.environ.get('TRACE_TREE')      # build with -DMZ_TREE_TRACE only: stamps of the fused head + tree-step kernel
+NAMES = ['head', 'backup: prefetch', 'backup: expand', 'backup: chain+slots', 'backup: root+minmax', '', '', '',
+         'select: root stats', 'select: root level', 'select: other level'] if TREE else ['prologue', 'stage set-up', 'MFMA section', 'commit / stores', 'barrier', 'after barrier', 'epilogue math']
+NAMES = [n for n in NAMES]
 wl = dict(bench.WORKLOADS['tictactoe_4096x25'])
 dev = torch.device('cuda', 0)
 move = bench.NetworkMove(wl, dev, 1234, 1)
@@ -22,5 +25,6 @@ used = out[:, PH] > 0
 clk, cnt = out[used, :PH].astype(np.float64) / launches, out[used, PH:].astype(np.float64) / launches
 print(int(used.sum()), 'wavefronts; shader clocks per wavefront and launch')
 for i, nm in enumerate(NAMES):
+    if not nm: continue
     print(f'  {nm:14s} mean {clk[:, i].mean():8.0f}  max {clk[:, i].max():8.0f}   x{cnt[:, i].mean():5.1f}  -> {clk[:, i].sum() / max(cnt[:, i].sum(), 1):7.0f} each')
 print('  total          mean %8.0f  max %8.0f' % (clk.sum(1).mean(), clk.sum(1).max()))
