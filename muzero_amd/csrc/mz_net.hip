@@ -690,6 +690,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
     __shared__ int4 sDesc[24];
+    __shared__ float sBias[10 * 128];                // conv bias + action-plane bias of the current cell, per action;
+                                                     // [9*128..]: the cell's 128 reward-head weights
+#if MZ_EXP_H == 4
+    __shared__ float sPad[20 * 1024];                // experiment: one workgroup per CU
+    if (B < 0) sPad[threadIdx.x] = 1.f;
+#endif
     auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
@@ -703,6 +709,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     const int n = wave * 32 + (lane & 31);
     const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_h) + n * 2 + (lane >> 5);   // + weights offset / 4
 
+    // Every load in the loop body is issued BEFORE the stage's weight loads: vmcnt is in-order, so a load issued in an
+    // epilogue would have to drain the next stage's twenty loads behind which nothing else needs to wait.
+    const float dense_bias = w.dyn_dense_b[n];
     BFrag bw;
     const int4 D0 = w.job_desc[dbase];
     if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
@@ -790,6 +799,18 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
+        float bt[5];
+        if (kind == 0 && first_tap) {
+            // first tap of a cell: its bias table (conv bias + the action plane's valid taps: the one-hot encoder's
+            // planes are constant per cell, network.py:14-40) for all nine actions, requested ahead of this stage's
+            // weight loads and parked in LDS at the end of the stage; the last tap's epilogue reads it from there
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int idx = tid + kThreads * i;
+                bt[i] = idx < 9 * 128 ? w.dyn_actbias[((idx >> 7) * 9 + cell) * 128 + (idx & 127)]
+                                      : w.dyn_reward_w[cell * 128 + (idx & 127)];      // idx in [1152, 1280)
+            }
+        }
         if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
         MZ_TRACE_NW(1);                              // stage set-up
         // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
@@ -800,13 +821,19 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         MZ_TRACE_NW(2);                              // MFMA section
         if (kind == 2) accp = acc;
         if (kind == 0) {
-            if (last_tap) {       // last tap: + conv bias + action-plane bias (the one-hot encoder's planes are
-                                  // constant per cell: network.py:14-40), relu -> sX (games/tictactoe.py:189)
-                float ab[16];
+            if (first_tap) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
+                for (int i = 0; i < 5; ++i) {
+                    const int idx = tid + kThreads * i;
+                    sBias[idx] = bt[i];
+                }
+            }
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_split(sX, acc_row(0, r, lane), n, fmaxf(acc[r] + ab[r], 0.f));
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(0, r, lane);
+                    store_split(sX, row, n, fmaxf(acc[r] + sBias[sAct[row] * 128 + n], 0.f));
+                }
             }
             MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);                          // epilogue
@@ -814,11 +841,10 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
-            const float bn = w.dyn_dense_b[n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(0, r, lane);
-                const float v = fmaxf(acc[r] + bn, 0.f);
+                const float v = fmaxf(acc[r] + dense_bias, 0.f);
                 store_split(sH, row, n, v);
                 if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;   // f32, unsplit
             }
@@ -829,10 +855,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 const int row = tid >> 2, q = tid & 3;
                 float sdot = 0.f;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) sdot += load_split(sH, row, q * 32 + j) * w.dyn_reward_w[cell * 128 + q * 32 + j];
+                for (int j = 0; j < 32; ++j) sdot += load_split(sH, row, q * 32 + j) * sBias[9 * 128 + q * 32 + j];
                 sdot += __shfl_xor(sdot, 1, 4);
                 sdot += __shfl_xor(sdot, 2, 4);
-                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
+                int grow = row0 + row;
+                asm volatile("" : "+v"(grow));      // address formed here, not hoisted out of the loop into a spilled pair
+                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)grow * 9 + cell] = sdot;
             }
         } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
             if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
@@ -1037,6 +1065,10 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
                                            const float* __restrict__ rpart, float* sX, float* sH, float (*sOut)[12]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, q = lane >> 4;
+    // biases first: a load issued after the MFMAs would show its whole latency
+    const int n0 = wave * 32 + n16;
+    const float b0 = w.pred_dense_b[n0], b1 = w.pred_dense_b[n0 + 16];
+    const float hb = w.pred_head_b[n16];
     float2 bF[2][16], hF[16];
     {
         const float2* wp = reinterpret_cast<const float2*>(w.pred_dense_p) + (size_t)(wave * 32 + n16) * 4 + q;
@@ -1090,8 +1122,6 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[0][kb].y, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[1][kb].y, acc1, 0, 0, 0);
         }
-        const int n0 = wave * 32 + n16;
-        const float b0 = w.pred_dense_b[n0], b1 = w.pred_dense_b[n0 + 16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // C/D layout 16x16: row = 4*(lane/16) + i, col = lane%16
             sH[(4 * q + i) * kLd + n0] = fmaxf(acc0[i] + b0, 0.f);
@@ -1113,7 +1143,6 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb + 1].y, hF[kb + 1].y, acc1, 0, 0, 0);
         }
         if (n16 < 10) {
-            const float hb = w.pred_head_b[n16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v = acc0[i] + acc1[i] + hb;
@@ -1420,10 +1449,10 @@ __device__ __forceinline__ f32x4 mma16(const float* sA, const BFrag16& b, int la
     }
     return acc0 + acc1;
 }
-// dot of a 128-float LDS row with 128 weights by the 16 threads of a row (q = 0..15 takes 8 floats each); all get the sum
-__device__ __forceinline__ float dot8x16(const float* h, const float* wv, int q) {
+// dot of a 128-float LDS row with 128 weights by the 16 threads of a row (q = 0..15 takes 8 floats each, its 8 weights
+// already in registers); all 16 get the sum
+__device__ __forceinline__ float dot8x16(const float* h, const float4& b0, const float4& b1, int q) {
     const float4 a0 = *reinterpret_cast<const float4*>(h + 8 * q), a1 = *reinterpret_cast<const float4*>(h + 8 * q + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(wv + 8 * q), b1 = *reinterpret_cast<const float4*>(wv + 8 * q + 4);
     float s = a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
     s += __shfl_xor(s, 1, 16);
     s += __shfl_xor(s, 2, 16);
@@ -1452,6 +1481,18 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
     const int row0 = blockIdx.x * ROWS;
     float* sX = sBuf[0];
     float* sH = sBuf[1];
+    // Every bias and head weight this thread will need, requested first: vmcnt is in-order, so a load issued in an
+    // epilogue would wait for the weight fragments of the stage after next that are requested ahead of it.
+    const int hq = tid & 15;                             // this thread's eighth of a head's 128 weights
+    const float bias_hidden = (INITIAL ? w.rep_dense_b : w.dyn_dense_b)[n];
+    const float bias_conv = INITIAL ? 0.f : w.dyn_conv_b[n], plane = INITIAL ? 0.f : w.dyn_plane[n];
+    const float bias_rdense = INITIAL ? 0.f : w.dyn_rdense_b[n];
+    const float bias_p1 = w.pred_dense1_b[n], bias_p2 = w.pred_dense2_b[n], bias_value = w.pred_value_b[n];
+    const float4* rwp = reinterpret_cast<const float4*>(w.dyn_reward_w + 8 * hq);
+    const float4* pwp = reinterpret_cast<const float4*>(w.pred_policy_w + 8 * hq);
+    const float4 rw0 = INITIAL ? make_float4(0.f, 0.f, 0.f, 0.f) : rwp[0], rw1 = INITIAL ? rw0 : rwp[1];
+    const float4 pw00 = pwp[0], pw01 = pwp[1], pw10 = pwp[32], pw11 = pwp[33];
+    const float policy_b0 = w.pred_policy_b[0], policy_b1 = w.pred_policy_b[1];
     BFrag16 b0, b1;
     load_b16(b0, INITIAL ? w.rep_dense_p : w.dyn_conv_p, lane, wave);
     if (tid < ROWS) {
@@ -1517,11 +1558,10 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
         __syncthreads();
         // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
         acc = mma16(sH, b0, lane);
-        const float bn = w.dyn_conv_b[n], pn = w.dyn_plane[n];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * q4 + i;
-            sX[row * kLd + n] = fmaxf(acc[i] + bn + sAct[row] * pn, 0.f);
+            sX[row * kLd + n] = fmaxf(acc[i] + bias_conv + sAct[row] * plane, 0.f);
         }
         load_b16(b0, w.dyn_rdense_p, lane, wave);
         __syncthreads();
@@ -1529,11 +1569,10 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
         load_b16(b1, w.pred_dense1_p, lane, wave);
     }
     {   // hidden state out (both modes); sH's previous contents (the gathered input) are no longer read
-        const float bn = (INITIAL ? w.rep_dense_b : w.dyn_dense_b)[n];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * q4 + i;
-            const float v = fmaxf(acc[i] + bn, 0.f);
+            const float v = fmaxf(acc[i] + bias_hidden, 0.f);
             sH[row * kLd + n] = v;
             if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 128 + n] = v;
         }
@@ -1545,10 +1584,10 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
     if (!INITIAL) {
         // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114)
         acc = mma16(sH, b0, lane);
-        store(acc, w.dyn_rdense_b[n], sX, true);
+        store(acc, bias_rdense, sX, true);
         __syncthreads();
         if (rowthread) {
-            const float s = dot8x16(sX + row * kLd, w.dyn_reward_w, q);
+            const float s = dot8x16(sX + row * kLd, rw0, rw1, q);
             if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
         }
         __syncthreads();
@@ -1556,16 +1595,16 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
     // prediction: Dense relu, Dense relu (games/cartpole.py:121-124); b1 = pred_dense1 in both modes
     load_b16(b0, w.pred_dense2_p, lane, wave);
     acc = mma16(sH, b1, lane);
-    store(acc, w.pred_dense1_b[n], sX, true);
+    store(acc, bias_p1, sX, true);
     load_b16(b1, w.pred_value_p, lane, wave);
     __syncthreads();
     acc = mma16(sX, b0, lane);
     __syncthreads();
-    store(acc, w.pred_dense2_b[n], sH, true);
+    store(acc, bias_p2, sH, true);
     __syncthreads();
     // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
     acc = mma16(sH, b1, lane);
-    store(acc, w.pred_value_b[n], sX, false);
+    store(acc, bias_value, sX, false);
     __syncthreads();
     if (rowthread) {
         float* z = sX + row * kLd;
@@ -1595,10 +1634,10 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
             out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
         }
         // policy logits: Dense 2 (:127)
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const float s = dot8x16(sH + row * kLd, w.pred_policy_w + o * 128, q);
-            if (q == 0 && live) out_logits[(size_t)b * 2 + o] = s + w.pred_policy_b[o];
+        const float s0 = dot8x16(sH + row * kLd, pw00, pw01, q), s1 = dot8x16(sH + row * kLd, pw10, pw11, q);
+        if (q == 0 && live) {
+            out_logits[(size_t)b * 2] = s0 + policy_b0;
+            out_logits[(size_t)b * 2 + 1] = s1 + policy_b1;
         }
     }
 }
