@@ -585,9 +585,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
 // Operand images: weights pre-split on the host (Packer::add_split_f16, same bytes and the same register ring as the
 // f32 fragments); activation tiles in LDS as [row][128 h | 128 l] halfs on the f32 tile's 528-byte row stride, so the
 // fragment reads keep the f32 kernel's conflict-free geometry.
-#ifndef MZ_EXP_H
-#define MZ_EXP_H 0
-#endif
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int kLdH = 2 * kLd;        // tile row stride in halfs
@@ -603,13 +600,11 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
 __device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
     _Float16 h, l;
     split_f16(v, h, l);
-#if MZ_EXP_H != 1
     const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
     const unsigned other = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);   // lane ^ 1
     const bool odd = n & 1;
     const unsigned word = odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
     *reinterpret_cast<unsigned*>(tile + row * kLdH + (odd ? 128 + n - 1 : n)) = word;
-#endif
 }
 __device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
     return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
@@ -631,16 +626,12 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
-#if MZ_EXP_H != 2
     b.v[2 * T] = wnext[(2 * T) * 256];
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
-#endif
-#if MZ_EXP_H != 3
     if (T >= 6) {                                   // the tile two stages ahead, requested once stg has been committed
         stg[2 * (T - 6)] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6)] + src);
         stg[2 * (T - 6) + 1] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6) + 1] + src);
     }
-#endif
     // pin the interleave: this block's LDS fragment reads, its three MFMAs, then its VMEM reads
     if (T + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -692,10 +683,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     __shared__ int4 sDesc[24];
     __shared__ float sBias[10 * 128];                // conv bias + action-plane bias of the current cell, per action;
                                                      // [9*128..]: the cell's 128 reward-head weights
-#if MZ_EXP_H == 4
-    __shared__ float sPad[20 * 1024];                // experiment: one workgroup per CU
-    if (B < 0) sPad[threadIdx.x] = 1.f;
-#endif
     auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);

@@ -175,6 +175,40 @@ def test_prefix_select_with_tied_priors(shape, mode, ad):
         pool.close()
 
 
+@pytest.mark.parametrize('use_logits', [False, True])
+def test_native_injected_move_equals_stepwise_calls(use_logits, ad):
+    """mz_search_move_injected enqueues root expansion, noise and N simulations from native code: same trees as the same
+    sequence of single calls (and therefore as the C oracle, which the stepwise path is held to above)."""
+    import torch
+    T, A, N = 96, 18, 30
+    inp = synthetic_inputs(T, A, N, seed=606, reward_mode='uniform', legal_mode='ragged')
+    kw = dict(num_trees=T, num_actions=A, max_simulations=N, num_players=1, discount=0.997, default_value=0.0,
+              known_bounds=None)
+    step = hip_pool(**kw)
+    want = run_synthetic_on_pool(step, inp, ad, fused=True, temperature=1.0, use_logits=use_logits)
+    native = hip_pool(**kw)
+    key = 'logits' if use_logits else 'priors'
+    parent, action = native.search_injected(ad.put(inp[key]), ad.put(inp['rewards']), ad.put(inp['values']),
+                                            noise=ad.put(inp['noise']), frac=0.25, legal=ad.put(inp['legal']),
+                                            n_legal=ad.put(inp['n_legal']), logits=use_logits)
+    visits, root_value, minmax, policy = (ad.get(x) for x in native.root_stats())
+    np.testing.assert_array_equal(visits, want['visits'])
+    np.testing.assert_array_equal(root_value, want['root_value'])
+    np.testing.assert_array_equal(minmax, want['minmax'])
+    np.testing.assert_array_equal(policy, want['policy'])
+    chosen = ad.get(native.select_action(ad.put(inp['u']), ad.put(np.full(T, 1.0, np.float64))))
+    np.testing.assert_array_equal(chosen, want['action'])
+    np.testing.assert_array_equal(native.counters()[:2], want['counters'][:2])
+    for t in range(0, T, 17):
+        if inp['n_legal'][t]:
+            for e in (0, 1, N // 2, N):
+                a, b = native.read_block(t, e), step.read_block(t, e)
+                for k in ('actions', 'count', 'value_sum', 'prior', 'child'):
+                    np.testing.assert_array_equal(a[k], b[k])
+    step.close()
+    native.close()
+
+
 def test_pool_is_reusable_across_moves(ad):
     """reset() + expand_roots() starts a fresh search in the same memory (agent.py:220-221: no tree reuse)."""
     from oracle import c_oracle
