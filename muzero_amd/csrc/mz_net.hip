@@ -590,21 +590,32 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int kLdH = 2 * kLd;        // tile row stride in halfs
 constexpr float kSplit = 2048.f, kUnsplit = 1.f / 2048.f;
 
+// Round-toward-zero conversions (v - h is exact whatever the rounding of h; the residual is then < 1 ulp of h instead of
+// half of one, still 21 bits in all) -- the packed conversion of the gather commit, so that a value splits into the same
+// (h, l) wherever it is split: by the stage that produces it (split workspace) or by the stages that gather it.
 __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
-    h = (_Float16)v;
-    l = (_Float16)((v - (float)h) * kSplit);
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v, 0.f))[0];
+    l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v - (float)h) * kSplit, 0.f))[0];
 }
-// Writes element (row, n) of a split tile.  Called by all 64 lanes with n = (a multiple of 32) + lane % 32 and a row that
-// depends on lane / 32 only: lanes n and n^1 trade their (h, l) pairs, the even one writes both h's, the odd one both
-// l's -- one 4-byte LDS write per lane instead of two 2-byte ones.
-__device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
+// The split image of a row of 128 values is [128 h | 128 l] halfs.  Element n of a row, held by a lane whose neighbour
+// lane ^ 1 holds element n ^ 1 of the same row (n = a multiple of 32 + lane % 32): the two lanes trade their (h, l)
+// pairs, the even one ends with both h's, the odd one with both l's -- one 4-byte word per lane instead of two 2-byte
+// ones.  Returns the word and sets `pos` to its position in the row image, in halfs.
+__device__ __forceinline__ unsigned split_word(float v, int n, int& pos) {
     _Float16 h, l;
     split_f16(v, h, l);
     const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
     const unsigned other = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);   // lane ^ 1
     const bool odd = n & 1;
-    const unsigned word = odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
-    *reinterpret_cast<unsigned*>(tile + row * kLdH + (odd ? 128 + n - 1 : n)) = word;
+    pos = odd ? 128 + n - 1 : n;
+    return odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
+}
+// Writes element (row, n) of a split tile in LDS; called by all 64 lanes.
+__device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
+    int pos;
+    const unsigned word = split_word(v, n, pos);
+    *reinterpret_cast<unsigned*>(tile + row * kLdH + pos) = word;
 }
 __device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
     return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
@@ -668,7 +679,11 @@ __device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16&
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
 }
 
-// Same jobs, stages, grid and outputs as ttt_job_kernel.
+// Same jobs, stages, grid and outputs as ttt_job_kernel.  SPLIT_IO: the hidden-state rows in HBM (gathered parents and
+// the rows written) are split images ([128 h | 128 l] halfs per cell, the bytes of 128 floats) instead of floats -- the
+// workspace of a native move (mz_search_move), where nobody else reads them: a gathered row is then copied into the tile
+// as it is, instead of being split by every one of the up to nine stages that read it.
+template <bool SPLIT_IO>
 __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B, const float* __restrict__ in_base,
                                                                 const int* __restrict__ parent_block, long block_stride,
                                                                 const int* __restrict__ action,
@@ -733,6 +748,10 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
             const bool ok = (svalid >> i) & 1u;
+            if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
+                *reinterpret_cast<float4*>(buf + r * kLdH + c4 * 8) = ok ? stg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
             const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
             // h by the packed round-toward-zero conversion (v - h is exact whatever the rounding of h; the residual is
             // then < 1 ulp of h instead of half of one, still 21 bits in all), l likewise
@@ -832,8 +851,14 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(0, r, lane);
                 const float v = fmaxf(acc[r] + dense_bias, 0.f);
-                store_split(sH, row, n, v);
-                if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;   // f32, unsplit
+                int pos;
+                const unsigned word = split_word(v, n, pos);
+                *reinterpret_cast<unsigned*>(sH + row * kLdH + pos) = word;
+                if (sRowOff[row] >= 0) {
+                    float* orow = out_hidden + (size_t)(row0 + row) * 1152 + cell * 128;
+                    if (SPLIT_IO) *reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(orow) + pos) = word;
+                    else orow[n] = v;                                                          // f32, unsplit
+                }
             }
             MZ_TRACE_NW(3);
             __syncthreads();
@@ -865,6 +890,30 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         }
         MZ_TRACE_NW(5);                              // after the barrier (reward dot)
     }
+}
+
+// f32 rows of 128 -> split images in place (the root hidden states of a native move).  One row per half wavefront:
+// every lane has its four floats before any lane writes.
+__global__ __launch_bounds__(kThreads) void split_rows_kernel(float* __restrict__ rows, long nrows) {
+    const long row = (long)blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
+    const int c4 = threadIdx.x & 31;
+    if (row >= nrows) return;
+    float* p = rows + row * 128;
+    const float4 v = *reinterpret_cast<const float4*>(p + c4 * 4);
+    f16x4 h, l;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 hj, lj;
+        split_f16(x[j], hj, lj);
+        h[j] = hj;
+        l[j] = lj;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    _Float16* q = reinterpret_cast<_Float16*>(p);
+    *reinterpret_cast<f16x4*>(q + c4 * 4) = h;
+    *reinterpret_cast<f16x4*>(q + 128 + c4 * 4) = l;
 }
 
 // Diagnostic twin of ttt_job_kernel with in-kernel segment stamps (tools/trace_cell.py); never used by the product path.
@@ -1681,6 +1730,7 @@ struct mz_net {
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
+    bool hidden_split = false;        // inside a native move: the hidden workspace holds split images (mz_net_begin_move)
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
     long long* trace = nullptr;       // diagnostic: per-workgroup timeline of the cell kernel (device, 3 x grid)
 };
@@ -2042,6 +2092,7 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
                      float* out_logits, float* out_value_raw) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
+    net->hidden_split = false;   // a move starts here; a native move that failed half way may have left it set
     if (batch == 0) return MZ_OK;
     MZ_REQUIRE(observation && out_hidden && out_value && out_logits, "observation/out_hidden/out_value/out_logits is NULL");
     MZ_HIP(hipSetDevice(net->device));
@@ -2104,9 +2155,9 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                                                                             action, out_hidden, net->ppart, net->rpart,
                                                                             nullptr);
             else
-                ttt_job_kernel_h<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                              bs, action, out_hidden, net->ppart,
-                                                                              net->rpart);
+                ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base,
+                                                                                     parent_block, bs, action, out_hidden,
+                                                                                     net->ppart, net->rpart);
         } else if (rows == 64)
             ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
                                                                    out_hidden, net->ppart, net->rpart, cell_order(),
@@ -2137,6 +2188,20 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
     }
     return launch_status("recurrent inference");
 }
+
+// Internal to the library (mz_pool_internal.h): a native move owns its hidden workspace, so the TicTacToe job kernel keeps
+// it as split images.  begin: converts the root rows written by the initial inference (block 0, T x H floats) in place.
+__attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, float* hidden_block0, int batch) {
+    if (net->kind != MZ_NET_TICTACTOE || job_f32()) return MZ_OK;
+    MZ_HIP(hipSetDevice(net->device));
+    const long nrows = (long)batch * 9;
+    split_rows_kernel<<<(unsigned)((nrows + kThreads / 32 - 1) / (kThreads / 32)), kThreads, 0, net->stream>>>(hidden_block0, nrows);
+    int s = launch_status("split_rows_kernel");
+    if (s != MZ_OK) return s;
+    net->hidden_split = true;
+    return MZ_OK;
+}
+__attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->hidden_split = false; }
 
 int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,
                             int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,
@@ -2169,10 +2234,14 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
         ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
                                                                     (long)block_stride, action, out_hidden, net->ppart,
                                                                     net->rpart, nullptr);
+    else if (net->hidden_split)
+        ttt_job_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                            (long)block_stride, action, out_hidden,
+                                                                            net->ppart, net->rpart);
     else
-        ttt_job_kernel_h<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                      (long)block_stride, action, out_hidden, net->ppart,
-                                                                      net->rpart);
+        ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                             (long)block_stride, action, out_hidden,
+                                                                             net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)

@@ -21,3 +21,9 @@ struct mz_pool {
 // mz_step / mz_expand_backprop check and returns the block the new nodes take; commit after a successful launch.
 int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block);
 void mz_pool_commit_backprop(mz_pool* pool, bool with_select);
+
+// A native move (mz_search_move) brackets its simulations with these: between them the network may keep the move's hidden
+// workspace in an internal format (mz_net.hip).  hidden_block0: the root hidden states just written by mz_infer_initial.
+struct mz_net;
+extern "C" int mz_net_begin_move(mz_net* net, float* hidden_block0, int batch);
+extern "C" void mz_net_end_move(mz_net* net);

@@ -22,6 +22,7 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
     } while (0)
     MZ_TRY_(mz_pool_reset(pool));
     MZ_TRY_(mz_infer_initial(net, T, io->observation, io->hidden, io->value, io->logits, nullptr));
+    MZ_TRY_(mz_net_begin_move(net, io->hidden, T));      // from here to the end the hidden workspace is the network's
     MZ_TRY_(mz_expand_roots_logits(pool, io->logits, io->legal, io->n_legal));
     MZ_TRY_(mz_add_root_noise(pool, io->noise, io->noise_frac));
     MZ_TRY_(mz_select(pool, io->parent_block, io->action));
@@ -38,6 +39,7 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
+    mz_net_end_move(net);
     MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
     if (io->out_action) MZ_TRY_(mz_select_action(pool, io->u, io->temperature, io->out_action));
 #undef MZ_TRY_
