@@ -637,8 +637,10 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+#ifndef MZ_EXP_NOW
     b.v[2 * T] = wnext[(2 * T) * 256];
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
+#endif
     if (T >= 6) {                                   // the tile two stages ahead, requested once stg has been committed
         stg[2 * (T - 6)] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6)] + src);
         stg[2 * (T - 6) + 1] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6) + 1] + src);
@@ -695,7 +697,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
-    __shared__ int4 sDesc[24];
     __shared__ float sBias[10 * 128];                // conv bias + action-plane bias of the current cell, per action;
                                                      // [9*128..]: the cell's 128 reward-head weights
     auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
@@ -715,8 +716,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     // epilogue would have to drain the next stage's twenty loads behind which nothing else needs to wait.
     const float dense_bias = w.dyn_dense_b[n];
     BFrag bw;
-    const int4 D0 = w.job_desc[dbase];
-    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
+    // stage descriptors: uniform addresses in the constant address space = scalar loads into SGPRs, one stage ahead of
+    // their use (nothing to broadcast, nothing on the vector memory or LDS queues)
+    typedef int __attribute__((ext_vector_type(4))) Desc;      // .x kind | flags, .y cell, .z tap, .w source cell
+    typedef const __attribute__((address_space(4))) Desc* DescPtr;
+    const DescPtr desc = (DescPtr)w.job_desc + dbase;
+    const Desc D0 = desc[0];
     load_b(bw, w.dyn_conv_h + (size_t)D0.z * 16384, lane, wave);
     if (tid < ROWS) {
         const int b = row0 + tid;
@@ -771,31 +776,34 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
     commit(tile(0));
     {   // stage 1's tile, if it gathers one, is on its way while stage 0 starts
-        const int4 D1 = w.job_desc[dbase + (d1 > 1 ? 1 : 0)];
+        const Desc D1 = desc[d1 > 1 ? 1 : 0];
         const int src1 = (d1 > 1 && (D1.x & 7) == 0) ? D1.w * 128 : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src1);
     }
     __syncthreads();
 
+    // rows with an output (game < B and a parent): one bit per row, shifted so that bit (r & 3) + 8 * (r >> 2) is this
+    // lane's accumulator register r
+    const unsigned rowmask = (unsigned)__ballot(sRowOff[lane & 31] >= 0);
+    const unsigned lanerows = rowmask >> (4 * (lane >> 5));
     f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
 #pragma unroll
     for (int r = 0; r < 16; ++r) accp[r] = 0.f;
     int buf = 0;
+    Desc Dc = D0, Dn = desc[d1 > 1 ? 1 : 0], Dn2 = desc[d1 > 2 ? 2 : 0];
     MZ_TRACE_DECL;
     MZ_TRACE_NW(0);                                  // prologue
 #pragma unroll 1
     for (int d = 0; d < d1; ++d) {
-        const int4 Dc = sDesc[d];
         const bool has_next = d + 1 < d1;
-        const int4 Dn = sDesc[has_next ? d + 1 : d];
-        const int4 Dn2 = sDesc[d + 2 < d1 ? d + 2 : d];
-        const bool gather2 = d + 2 < d1 && __builtin_amdgcn_readfirstlane(Dn2.x & 7) == 0;
-        const int nsrc2 = __builtin_amdgcn_readfirstlane(Dn2.w);
-        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
-        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
-        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
-        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
+        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on
+        const bool gather2 = d + 2 < d1 && (Dn2.x & 7) == 0;
+        const int nsrc2 = Dn2.w;
+        const int kind = Dc.x & 7, cell = Dc.y;
+        const int nkind = has_next ? Dn.x & 7 : kind;
+        const bool first_tap = (Dc.x & 8) != 0, last_tap = (Dc.x & 16) != 0;
+        const int ntap = has_next ? Dn.z : Dc.z, ncell = has_next ? Dn.y : Dc.y;
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
         const float* wn = nkind == 0 ? w.dyn_conv_h + (size_t)ntap * 16384
                         : nkind == 1 ? w.dyn_dense_h : w.pred_conv_h + (size_t)ncell * 16384;
@@ -847,6 +855,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(0, r, lane);
@@ -854,8 +863,8 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 int pos;
                 const unsigned word = split_word(v, n, pos);
                 *reinterpret_cast<unsigned*>(sH + row * kLdH + pos) = word;
-                if (sRowOff[row] >= 0) {
-                    float* orow = out_hidden + (size_t)(row0 + row) * 1152 + cell * 128;
+                if ((lanerows >> ((r & 3) + 8 * (r >> 2))) & 1u) {
+                    float* orow = ocell + (unsigned)row * 1152u;
                     if (SPLIT_IO) *reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(orow) + pos) = word;
                     else orow[n] = v;                                                          // f32, unsplit
                 }
@@ -872,14 +881,17 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 sdot += __shfl_xor(sdot, 2, 4);
                 int grow = row0 + row;
                 asm volatile("" : "+v"(grow));      // address formed here, not hoisted out of the loop into a spilled pair
-                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)grow * 9 + cell] = sdot;
+                if (q == 0 && ((rowmask >> row) & 1u)) rpart[(size_t)grow * 9 + cell] = sdot;
             }
         } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
             if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
+                int prow = row0;
+                asm volatile("" : "+s"(prow));      // addresses formed here, not sixteen pointers hoisted out of the loop
+                float* const pjob = ppart + (size_t)prow * 1152 + job * 128;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = acc_row(0, r, lane);
-                    if (sRowOff[row] >= 0) ppart[(size_t)(row0 + row) * 1152 + job * 128 + n] = accp[r];
+                    if ((lanerows >> ((r & 3) + 8 * (r >> 2))) & 1u) pjob[(unsigned)row * 1152u + n] = accp[r];
                 }
             }
             MZ_TRACE_NW(6);                          // epilogue math
@@ -889,6 +901,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             if (gather) buf ^= 1;
         }
         MZ_TRACE_NW(5);                              // after the barrier (reward dot)
+        Dc = Dn;
+        Dn = Dn2;
+        Dn2 = Dn3;
     }
 }
 
