@@ -797,7 +797,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 #pragma unroll 1
     for (int d = 0; d < d1; ++d) {
         const bool has_next = d + 1 < d1;
-        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on
         const bool gather2 = d + 2 < d1 && (Dn2.x & 7) == 0;
         const int nsrc2 = Dn2.w;
         const int kind = Dc.x & 7, cell = Dc.y;
@@ -810,6 +809,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         const bool gather = has_next && nkind == 0;
         const _Float16* sA = kind == 0 ? tile(buf) : kind == 1 ? sX : sH;
         if (kind == 1 || first_tap) {
+            asm volatile("");                   // a uniform branch, not thirty-two selects per stage
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
@@ -825,7 +825,10 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                                       : w.dyn_reward_w[cell * 128 + (idx & 127)];      // idx in [1152, 1280)
             }
         }
-        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
+        if (kind == 2) {                    // one call site: the prediction partial rides in acc for its stage
+            asm volatile("");
+            acc = accp;
+        }
         MZ_TRACE_NW(1);                              // stage set-up
         // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
         // stage's MFMAs; the tile after it is requested at the end of this stage
@@ -833,7 +836,14 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             if (gather) commit(tile(buf ^ 1));
         });
         MZ_TRACE_NW(2);                              // MFMA section
-        if (kind == 2) accp = acc;
+        // the descriptor three stages on, used from the next iteration: requested here, after the MFMA section (a scalar
+        // load in flight turns every LDS wait into a wait for everything), and back long before the stage's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];
+        if (kind == 2) {
+            asm volatile("");
+            accp = acc;
+        }
         if (kind == 0) {
             if (first_tap) {
 #pragma unroll
