@@ -598,30 +598,28 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
     h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v, 0.f))[0];
     l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v - (float)h) * kSplit, 0.f))[0];
 }
-// The split image of a row of 128 values is [128 h | 128 l] halfs.  Element n of a row, held by a lane whose neighbour
-// lane ^ 1 holds element n ^ 1 of the same row (n = a multiple of 32 + lane % 32): the two lanes trade their (h, l)
-// pairs, the even one ends with both h's, the odd one with both l's -- one 4-byte word per lane instead of two 2-byte
-// ones.  Returns the word and sets `pos` to its position in the row image, in halfs.
-__device__ __forceinline__ unsigned split_word(float v, int n, int& pos) {
-    _Float16 h, l;
-    split_f16(v, h, l);
-    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);   // lane ^ 1
-    const bool odd = n & 1;
-    pos = odd ? 128 + n - 1 : n;
-    return odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
-}
-// Writes element (row, n) of a split tile in LDS; called by all 64 lanes.
-__device__ __forceinline__ void store_split(_Float16* tile, int row, int n, float v) {
-    int pos;
-    const unsigned word = split_word(v, n, pos);
-    *reinterpret_cast<unsigned*>(tile + row * kLdH + pos) = word;
+// The split image of a row of 128 values is [128 h | 128 l] halfs.  Four consecutive values of a row -> their four h and
+// four l halfs, 8 bytes each (two packed conversions and packed f32 arithmetic per pair).
+__device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    unsigned hw[2], lw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f16x2 hh = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]));
+        const f32x2 vv = {v[2 * i], v[2 * i + 1]}, hf = {(float)hh[0], (float)hh[1]};
+        const f32x2 d = (vv - hf) * kSplit;
+        hw[i] = __builtin_bit_cast(unsigned, hh);
+        lw[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
+    }
+    h = make_uint2(hw[0], hw[1]);
+    l = make_uint2(lw[0], lw[1]);
 }
 __device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
     return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
 }
 
-// One 16-k block of a stage: acc += ah*bh, acc2 += ah*bl + al*bh.  The block's two weight registers are re-loaded with
+// One 16-k block of a stage: acc += bh*ah, acc2 += bl*ah + bh*al (a = activations, b = weights).  The block's two weight registers are re-loaded with
 // the NEXT stage's fragments right after (in-place ring), the activation fragments are read two blocks ahead, and the
 // next tile's gather rides on the first four blocks.
 template <int T>
@@ -634,9 +632,12 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     }
     const f16x8 ah = __builtin_bit_cast(f16x8, af[T % 3][0]), al = __builtin_bit_cast(f16x8, af[T % 3][1]);
     const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * T]), bl = __builtin_bit_cast(f16x8, b.v[2 * T + 1]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+    // weights as the row operand: the product comes out transposed, a lane holds for ITS tile row (lane % 32) the
+    // columns 8 q + 4 (lane / 32) + {0..3} of the wave's 32 in registers 4 q + {0..3} -- runs of four consecutive columns,
+    // which is what the epilogues' packed splits and 8-byte stores want
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc2, 0, 0, 0);
 #ifndef MZ_EXP_NOW
     b.v[2 * T] = wnext[(2 * T) * 256];
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
@@ -685,6 +686,15 @@ __device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16&
 // the rows written) are split images ([128 h | 128 l] halfs per cell, the bytes of 128 floats) instead of floats -- the
 // workspace of a native move (mz_search_move), where nobody else reads them: a gathered row is then copied into the tile
 // as it is, instead of being split by every one of the up to nine stages that read it.
+#ifndef MZ_EXP_SYNC
+#define MZ_EXP_SYNC __syncthreads()
+#endif
+#ifndef MZ_EXP_EPI
+#define MZ_EXP_EPI true
+#endif
+#ifndef MZ_EXP_COMMIT
+#define MZ_EXP_COMMIT true
+#endif
 template <bool SPLIT_IO>
 __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B, const float* __restrict__ in_base,
                                                                 const int* __restrict__ parent_block, long block_stride,
@@ -697,8 +707,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
-    __shared__ float sBias[10 * 128];                // conv bias + action-plane bias of the current cell, per action;
-                                                     // [9*128..]: the cell's 128 reward-head weights
+    __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // conv bias + action-plane bias of the current cell,
+                                                     // per action; [9*128..]: the cell's 128 reward-head weights;
+                                                     // [10*128..]: the dense layer's bias
     auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 
     // Every load in the loop body is issued BEFORE the stage's weight loads: vmcnt is in-order, so a load issued in an
     // epilogue would have to drain the next stage's twenty loads behind which nothing else needs to wait.
-    const float dense_bias = w.dyn_dense_b[n];
+    if (tid < 128) sBias[10 * 128 + tid] = w.dyn_dense_b[tid];
     BFrag bw;
     // stage descriptors: uniform addresses in the constant address space = scalar loads into SGPRs, one stage ahead of
     // their use (nothing to broadcast, nothing on the vector memory or LDS queues)
@@ -783,10 +794,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     }
     __syncthreads();
 
-    // rows with an output (game < B and a parent): one bit per row, shifted so that bit (r & 3) + 8 * (r >> 2) is this
-    // lane's accumulator register r
+    // rows with an output (game < B and a parent): one bit per row
     const unsigned rowmask = (unsigned)__ballot(sRowOff[lane & 31] >= 0);
-    const unsigned lanerows = rowmask >> (4 * (lane >> 5));
+    // the accumulators are transposed (mma_block_h): this lane's tile row, its action, and its first column
+    const int lrow = lane & 31, lcol = wave * 32 + 4 * (lane >> 5);
+    const bool lrow_ok = (rowmask >> lrow) & 1u;
+    const int lact = sAct[lrow];
     f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
 #pragma unroll
     for (int r = 0; r < 16; ++r) accp[r] = 0.f;
@@ -833,7 +846,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
         // stage's MFMAs; the tile after it is requested at the end of this stage
         mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather2 ? nsrc2 * 128 : 0, stg, [&] {
-            if (gather) commit(tile(buf ^ 1));
+            if (gather && MZ_EXP_COMMIT) commit(tile(buf ^ 1));
         });
         MZ_TRACE_NW(2);                              // MFMA section
         // the descriptor three stages on, used from the next iteration: requested here, after the MFMA section (a scalar
@@ -852,37 +865,53 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                     sBias[idx] = bt[i];
                 }
             }
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+            if (last_tap && MZ_EXP_EPI) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(0, r, lane);
-                    store_split(sX, row, n, fmaxf(acc[r] + sBias[sAct[row] * 128 + n], 0.f));
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sBias + lact * 128 + lcol + 8 * q);
+                    const float v[4] = {fmaxf(acc[4 * q] + bq.x, 0.f), fmaxf(acc[4 * q + 1] + bq.y, 0.f),
+                                        fmaxf(acc[4 * q + 2] + bq.z, 0.f), fmaxf(acc[4 * q + 3] + bq.w, 0.f)};
+                    uint2 h, l;
+                    split4(v, h, l);
+                    *reinterpret_cast<uint2*>(sX + lrow * kLdH + lcol + 8 * q) = h;
+                    *reinterpret_cast<uint2*>(sX + lrow * kLdH + 128 + lcol + 8 * q) = l;
                 }
             }
             MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);                          // epilogue
-            __syncthreads();
+            MZ_EXP_SYNC;
             MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
+            if (MZ_EXP_EPI) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(0, r, lane);
-                const float v = fmaxf(acc[r] + dense_bias, 0.f);
-                int pos;
-                const unsigned word = split_word(v, n, pos);
-                *reinterpret_cast<unsigned*>(sH + row * kLdH + pos) = word;
-                if ((lanerows >> ((r & 3) + 8 * (r >> 2))) & 1u) {
-                    float* orow = ocell + (unsigned)row * 1152u;
-                    if (SPLIT_IO) *reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(orow) + pos) = word;
-                    else orow[n] = v;                                                          // f32, unsplit
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol + 8 * q);
+                    const float v[4] = {fmaxf(acc[4 * q] + bq.x, 0.f), fmaxf(acc[4 * q + 1] + bq.y, 0.f),
+                                        fmaxf(acc[4 * q + 2] + bq.z, 0.f), fmaxf(acc[4 * q + 3] + bq.w, 0.f)};
+                    uint2 h, l;
+                    split4(v, h, l);
+                    *reinterpret_cast<uint2*>(sH + lrow * kLdH + lcol + 8 * q) = h;
+                    *reinterpret_cast<uint2*>(sH + lrow * kLdH + 128 + lcol + 8 * q) = l;
+                    if (!SPLIT_IO && lrow_ok)                                                   // f32, unsplit
+                        *reinterpret_cast<float4*>(ocell + (unsigned)lrow * 1152u + lcol + 8 * q) =
+                            make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
             MZ_TRACE_NW(3);
-            __syncthreads();
+            MZ_EXP_SYNC;
             MZ_TRACE_NW(4);
-            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
+            if (SPLIT_IO && MZ_EXP_EPI) {          // sH is the row image the workspace wants: copied out 16 bytes a thread
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
+                    if ((svalid >> i) & 1u)
+                        *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + c4 * 4) =
+                            *reinterpret_cast<const float4*>(sH + r * kLdH + c4 * 8);
+                }
+            }
+            if (tid < ROWS * 4 && MZ_EXP_EPI) {                  // reward head partial (games/tictactoe.py:193-195)
                 const int row = tid >> 2, q = tid & 3;
                 float sdot = 0.f;
 #pragma unroll
@@ -898,15 +927,16 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 int prow = row0;
                 asm volatile("" : "+s"(prow));      // addresses formed here, not sixteen pointers hoisted out of the loop
                 float* const pjob = ppart + (size_t)prow * 1152 + job * 128;
+                if (lrow_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(0, r, lane);
-                    if ((lanerows >> ((r & 3) + 8 * (r >> 2))) & 1u) pjob[(unsigned)row * 1152u + n] = accp[r];
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(pjob + (unsigned)lrow * 1152u + lcol + 8 * q) =
+                            make_float4(accp[4 * q], accp[4 * q + 1], accp[4 * q + 2], accp[4 * q + 3]);
                 }
             }
             MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);
-            __syncthreads();
+            MZ_EXP_SYNC;
             MZ_TRACE_NW(4);
             if (gather) buf ^= 1;
         }
