@@ -615,9 +615,6 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l) 
     h = make_uint2(hw[0], hw[1]);
     l = make_uint2(lw[0], lw[1]);
 }
-__device__ __forceinline__ float load_split(const _Float16* tile, int row, int n) {
-    return (float)tile[row * kLdH + n] + (float)tile[row * kLdH + 128 + n] * kUnsplit;
-}
 
 // One 16-k block of a stage: acc += bh*ah, acc2 += bl*ah + bh*al (a = activations, b = weights).  The block's two weight registers are re-loaded with
 // the NEXT stage's fragments right after (in-place ring), the activation fragments are read two blocks ahead, and the
@@ -710,13 +707,18 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // conv bias + action-plane bias of the current cell,
                                                      // per action; [9*128..]: the cell's 128 reward-head weights;
                                                      // [10*128..]: the dense layer's bias
+    __shared__ float sRew[4 * ROWS];                 // reward-head partials of the four waves' column ranges
     auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
     const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+#ifdef MZ_EXP_SAMEJOB
+    const int job = bi & 3, rb = (bi >> 2) * 8 + xl;
+#else
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
+#endif
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
     const int row0 = rb * ROWS;
     const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
@@ -885,11 +887,17 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
             if (MZ_EXP_EPI) {
+                float rdot = 0.f;                  // reward head (games/tictactoe.py:193-195): this lane's 16 columns
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol + 8 * q);
+                    const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol + 8 * q);
                     const float v[4] = {fmaxf(acc[4 * q] + bq.x, 0.f), fmaxf(acc[4 * q + 1] + bq.y, 0.f),
                                         fmaxf(acc[4 * q + 2] + bq.z, 0.f), fmaxf(acc[4 * q + 3] + bq.w, 0.f)};
+                    rdot = __builtin_fmaf(v[0], rw.x, rdot);
+                    rdot = __builtin_fmaf(v[1], rw.y, rdot);
+                    rdot = __builtin_fmaf(v[2], rw.z, rdot);
+                    rdot = __builtin_fmaf(v[3], rw.w, rdot);
                     uint2 h, l;
                     split4(v, h, l);
                     *reinterpret_cast<uint2*>(sH + lrow * kLdH + lcol + 8 * q) = h;
@@ -898,6 +906,8 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                         *reinterpret_cast<float4*>(ocell + (unsigned)lrow * 1152u + lcol + 8 * q) =
                             make_float4(v[0], v[1], v[2], v[3]);
                 }
+                rdot += __shfl_xor(rdot, 32);      // the row's other sixteen columns of this wave
+                if (lane < 32) sRew[wave * ROWS + lrow] = rdot;
             }
             MZ_TRACE_NW(3);
             MZ_EXP_SYNC;
@@ -911,16 +921,11 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                             *reinterpret_cast<const float4*>(sH + r * kLdH + c4 * 8);
                 }
             }
-            if (tid < ROWS * 4 && MZ_EXP_EPI) {                  // reward head partial (games/tictactoe.py:193-195)
-                const int row = tid >> 2, q = tid & 3;
-                float sdot = 0.f;
-#pragma unroll
-                for (int j = 0; j < 32; ++j) sdot += load_split(sH, row, q * 32 + j) * sBias[9 * 128 + q * 32 + j];
-                sdot += __shfl_xor(sdot, 1, 4);
-                sdot += __shfl_xor(sdot, 2, 4);
-                int grow = row0 + row;
+            if (tid < ROWS && MZ_EXP_EPI) {
+                int grow = row0 + tid;
                 asm volatile("" : "+v"(grow));      // address formed here, not hoisted out of the loop into a spilled pair
-                if (q == 0 && ((rowmask >> row) & 1u)) rpart[(size_t)grow * 9 + cell] = sdot;
+                if ((rowmask >> tid) & 1u)
+                    rpart[(size_t)grow * 9 + cell] = (sRew[tid] + sRew[ROWS + tid]) + (sRew[2 * ROWS + tid] + sRew[3 * ROWS + tid]);
             }
         } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
             if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
