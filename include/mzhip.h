@@ -217,7 +217,9 @@ typedef struct mz_move_io {
     double noise_frac;             /* MCTSConfig.root_exploration_fraction */
     const double* u;               /* [T] f64 uniforms for the action sampling */
     const double* temperature;     /* [T] f64 */
-    float* hidden;                 /* workspace [N+1][T][H] f32: block s+1 = hidden states of simulation s */
+    float* hidden;                 /* workspace of [N+1][T][H] floats: block s+1 = hidden states of simulation s.
+                                      Scratch: its contents after the call are in the network's internal format
+                                      (TicTacToe: split-f16 images of the f32 rows), not f32 hidden states */
     float* logits;                 /* workspace [T, A] f32 */
     float* reward;                 /* workspace [T] f32 */
     float* value;                  /* workspace [T] f32 */

@@ -32,10 +32,6 @@
 #include <utility>
 #include <vector>
 
-#ifndef MZ_EXP_PRIO
-#define MZ_EXP_PRIO 0
-#endif
-
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -365,22 +361,16 @@ __device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BF
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc, 0, 0, 0);
-#ifndef MZ_EXP_NOVMEM
     b.v[KB] = wnext[KB * 256];
     if (KB < 4) stg[KB] = *reinterpret_cast<const float4*>(sptr[KB] + src);
-#endif
     // pin the interleave (hipcc otherwise sinks all 20 loads behind the last MFMA, right in front of the epilogue
     // that waits for them): one LDS fragment read, 4 MFMA, then this k-step's VMEM reads
-#ifndef MZ_EXP_NOSCHED
     if (KB + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#ifndef MZ_EXP_NOVMEM
     if (KB < 4)
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     else
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#endif
-#endif
 }
 
 template <int... KB>
@@ -427,9 +417,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
     // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
-#if MZ_EXP_PRIO == 1
-    if ((bi >> 5) & 1) __builtin_amdgcn_s_setprio(3);
-#endif
     const int row0 = rb * ROWS;
     const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
     const int n = wave * 32 + (lane & 31);
@@ -518,17 +505,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
             for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
         }
         if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
-#if MZ_EXP_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#elif MZ_EXP_PRIO == 3
-        __builtin_amdgcn_s_setprio(3);
-#endif
         mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
-#if MZ_EXP_PRIO == 2
-        __builtin_amdgcn_s_setprio(3);
-#elif MZ_EXP_PRIO == 3
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (kind == 2) accp = acc;
         if (kind == 0) {
             if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
@@ -559,12 +536,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
             if (gather) buf ^= 1;
             if (!has_next) copy_out(sX, ppart + job * 128, 1152);
         }
-#ifdef MZ_EXP_FENCE
-        if ((d % MZ_EXP_FENCE) == MZ_EXP_FENCE - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-#endif
     }
     if (trace && threadIdx.x == 0) {
         long long* tr = trace + 8 * (size_t)blockIdx.x;
@@ -635,10 +606,8 @@ __device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc2, 0, 0, 0);
-#ifndef MZ_EXP_NOW
     b.v[2 * T] = wnext[(2 * T) * 256];
     b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
-#endif
     if (T >= 6) {                                   // the tile two stages ahead, requested once stg has been committed
         stg[2 * (T - 6)] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6)] + src);
         stg[2 * (T - 6) + 1] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6) + 1] + src);
@@ -683,15 +652,6 @@ __device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16&
 // the rows written) are split images ([128 h | 128 l] halfs per cell, the bytes of 128 floats) instead of floats -- the
 // workspace of a native move (mz_search_move), where nobody else reads them: a gathered row is then copied into the tile
 // as it is, instead of being split by every one of the up to nine stages that read it.
-#ifndef MZ_EXP_SYNC
-#define MZ_EXP_SYNC __syncthreads()
-#endif
-#ifndef MZ_EXP_EPI
-#define MZ_EXP_EPI true
-#endif
-#ifndef MZ_EXP_COMMIT
-#define MZ_EXP_COMMIT true
-#endif
 template <bool SPLIT_IO>
 __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B, const float* __restrict__ in_base,
                                                                 const int* __restrict__ parent_block, long block_stride,
@@ -714,11 +674,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
     const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
-#ifdef MZ_EXP_SAMEJOB
-    const int job = bi & 3, rb = (bi >> 2) * 8 + xl;
-#else
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
-#endif
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
     const int row0 = rb * ROWS;
     const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
@@ -848,7 +804,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
         // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
         // stage's MFMAs; the tile after it is requested at the end of this stage
         mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather2 ? nsrc2 * 128 : 0, stg, [&] {
-            if (gather && MZ_EXP_COMMIT) commit(tile(buf ^ 1));
+            if (gather) commit(tile(buf ^ 1));
         });
         MZ_TRACE_NW(2);                              // MFMA section
         // the descriptor three stages on, used from the next iteration: requested here, after the MFMA section (a scalar
@@ -867,7 +823,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                     sBias[idx] = bt[i];
                 }
             }
-            if (last_tap && MZ_EXP_EPI) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bq = *reinterpret_cast<const float4*>(sBias + lact * 128 + lcol + 8 * q);
@@ -881,12 +837,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             }
             MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);                          // epilogue
-            MZ_EXP_SYNC;
+            __syncthreads();
             MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
-            if (MZ_EXP_EPI) {
+            {
                 float rdot = 0.f;                  // reward head (games/tictactoe.py:193-195): this lane's 16 columns
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -910,9 +866,9 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                 if (lane < 32) sRew[wave * ROWS + lrow] = rdot;
             }
             MZ_TRACE_NW(3);
-            MZ_EXP_SYNC;
+            __syncthreads();
             MZ_TRACE_NW(4);
-            if (SPLIT_IO && MZ_EXP_EPI) {          // sH is the row image the workspace wants: copied out 16 bytes a thread
+            if (SPLIT_IO) {          // sH is the row image the workspace wants: copied out 16 bytes a thread
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
@@ -921,7 +877,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
                             *reinterpret_cast<const float4*>(sH + r * kLdH + c4 * 8);
                 }
             }
-            if (tid < ROWS && MZ_EXP_EPI) {
+            if (tid < ROWS) {
                 int grow = row0 + tid;
                 asm volatile("" : "+v"(grow));      // address formed here, not hoisted out of the loop into a spilled pair
                 if ((rowmask >> tid) & 1u)
@@ -941,7 +897,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
             }
             MZ_TRACE_NW(6);                          // epilogue math
             MZ_TRACE_NW(3);
-            MZ_EXP_SYNC;
+            __syncthreads();
             MZ_TRACE_NW(4);
             if (gather) buf ^= 1;
         }
