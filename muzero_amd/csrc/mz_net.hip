@@ -139,7 +139,7 @@ struct TttDev {
     const float* pred_value_w;  // [128]
     const float* pred_policy_w; // [9][128]
     const float* pred_policy_b; // [9]
-    const float* pred_head_p;   // packed [16][128][8]: column 0 = value head, 1..9 = policy heads, others zero
+    const float* pred_head_p;   // split-f16 fragments (Packer::add_split16): column 0 = value head, 1..9 = policy heads
     const float* pred_head_b;   // [16]: value bias, 9 policy biases, zeros
     const float* dyn_conv_h;    // the three GEMM operands of the job kernel again, as split-f16 fragments (pack_split_f16)
     const float* dyn_dense_h;
@@ -1103,32 +1103,39 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
     }
 }
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
 // Prediction head of 16 games by one 256-thread workgroup: relu(sum of the NP partial products + bias)
 // (games/tictactoe.py:201) -> Dense 128 -> 128 relu (:204) -> value (tanh, :206) and the 9 policy logits (:208), and
-// the reward head's tanh over the 9 per-cell partial dots (:193-195).  16-row tiles on v_mfma_f32_16x16x4_f32: wave v
-// owns output columns 32v..32v+31 as two 16-column blocks (two independent accumulator chains); the MFMA's four k's
-// per step are k = 8*kb + 2*(lane/16) + h, h = 0,1, so a lane's operands for a kb are one 8-byte load each (packed
-// weights [kb][n][8], activations row-major in LDS).  The ten head outputs are one more 16-column block (wave 0).
+// the reward head's tanh over the 9 per-cell partial dots (:193-195).  Split-f16 arithmetic like the job kernel
+// (v = h + l/2048, three exact f16 products per f32 product) on v_mfma_f32_16x16x32_f16: a Dense layer is 4 k-steps x 3
+// MFMAs of 16 cycles per 16-column block instead of 32 f32 MFMAs of 32.  A lane's operand for k-step s is the 8 halfs
+// k = 32 s + 8 (lane / 16) .. + 7 of row / column lane % 16 (weights packed that way by Packer::add_split16, activations
+// as [game][128 h | 128 l] images in LDS).  Wave v owns the Dense layer's columns 32v .. 32v+31 as two 16-column blocks,
+// with the weights as the row operand: a lane then holds four consecutive columns of one game, split and stored 8 bytes
+// at a time.  The ten head outputs are one more 16-column block (wave 0).
 // Results: sOut[game][0..8] logits, [9] value, [10] reward.  Ends with a barrier.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <int NP, bool REWARD>
 __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, const float* __restrict__ ppart,
-                                           const float* __restrict__ rpart, float* sX, float* sH, float (*sOut)[12]) {
+                                           const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12]) {
+    _Float16* sX = reinterpret_cast<_Float16*>(sXF);
+    _Float16* sH = reinterpret_cast<_Float16*>(sHF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n16 = lane & 15, q = lane >> 4;
+    const int n16 = lane & 15, g = lane >> 4;
     // biases first: a load issued after the MFMAs would show its whole latency
-    const int n0 = wave * 32 + n16;
-    const float b0 = w.pred_dense_b[n0], b1 = w.pred_dense_b[n0 + 16];
+    const float4 db[2] = {*reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 4 * g),
+                          *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 16 + 4 * g)};
     const float hb = w.pred_head_b[n16];
-    float2 bF[2][16], hF[16];
+    float4 bF[2][4][2], hF[4][2];                    // [column block][k-step][h | l]
     {
-        const float2* wp = reinterpret_cast<const float2*>(w.pred_dense_p) + (size_t)(wave * 32 + n16) * 4 + q;
+        const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + ((size_t)(wave * 32 + n16) * 4 + g) * 2;
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            bF[0][kb] = wp[kb * 512];
-            bF[1][kb] = wp[kb * 512 + 64];
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bF[c][s][0] = wp[s * 1024 + c * 128];
+                bF[c][s][1] = wp[s * 1024 + c * 128 + 1];
+            }
     }
     {   // every load of the tile is issued before the first use
         const int c4 = tid & 31;
@@ -1142,64 +1149,89 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             for (int c = 0; c < NP; ++c) v[i][c] = pp[c * 32];
         }
         if (wave == 0) {
-            const float2* hp = reinterpret_cast<const float2*>(w.pred_head_p) + (size_t)n16 * 4 + q;
+            const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + ((size_t)n16 * 4 + g) * 2;
 #pragma unroll
-            for (int kb = 0; kb < 16; ++kb) hF[kb] = hp[kb * 512];
+            for (int s = 0; s < 4; ++s) {
+                hF[s][0] = hp[s * 1024];
+                hF[s][1] = hp[s * 1024 + 1];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float4 s = bn;
+            float4 t = bn;
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
-                s.x += v[i][c].x;
-                s.y += v[i][c].y;
-                s.z += v[i][c].z;
-                s.w += v[i][c].w;
+                t.x += v[i][c].x;
+                t.y += v[i][c].y;
+                t.z += v[i][c].z;
+                t.w += v[i][c].w;
             }
-            *reinterpret_cast<float4*>(sX + ((tid >> 5) + 8 * i) * kLd + 4 * c4) =
-                make_float4(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f), fmaxf(s.z, 0.f), fmaxf(s.w, 0.f));
+            const float x[4] = {fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
+            uint2 h, l;
+            split4(x, h, l);
+            _Float16* row = sX + ((tid >> 5) + 8 * i) * kLdH + 4 * c4;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
         }
     }
     __syncthreads();
     {
-        float2 aF[16];
-        const float* ap = sX + n16 * kLd + 2 * q;
+        const _Float16* ap = sX + n16 * kLdH + 8 * g;
+        float4 aF[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) aF[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s) {
+            aF[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
+            aF[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, bF[0][kb].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, bF[1][kb].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[0][kb].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, bF[1][kb].y, acc1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, aF[s][0]), al = __builtin_bit_cast(f16x8, aF[s][1]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {            // weights as the row operand: acc[c][i] = column 16c + 4g + i, game n16
+                const f16x8 bh = __builtin_bit_cast(f16x8, bF[c][s][0]), bl = __builtin_bit_cast(f16x8, bF[c][s][1]);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[c], 0, 0, 0);
+                acx[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[c], 0, 0, 0);
+                acx[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[c], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {            // C/D layout 16x16: row = 4*(lane/16) + i, col = lane%16
-            sH[(4 * q + i) * kLd + n0] = fmaxf(acc0[i] + b0, 0.f);
-            sH[(4 * q + i) * kLd + n0 + 16] = fmaxf(acc1[i] + b1, 0.f);
+        for (int c = 0; c < 2; ++c) {
+            const float bb[4] = {db[c].x, db[c].y, db[c].z, db[c].w};
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = fmaxf(acc[c][i] + acx[c][i] * kUnsplit + bb[i], 0.f);
+            uint2 h, l;
+            split4(x, h, l);
+            _Float16* row = sH + n16 * kLdH + wave * 32 + 16 * c + 4 * g;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
         }
     }
     __syncthreads();
     if (wave == 0) {
-        float2 aF[16];
-        const float* ap = sH + n16 * kLd + 2 * q;
+        const _Float16* ap = sH + n16 * kLdH + 8 * g;
+        float4 aF[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) aF[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // even / odd kb: two chains, added at the end
+        for (int s = 0; s < 4; ++s) {
+            aF[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
+            aF[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx0 = {0.f, 0.f, 0.f, 0.f}, acx1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 16; kb += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].x, hF[kb].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb + 1].x, hF[kb + 1].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb].y, hF[kb].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aF[kb + 1].y, hF[kb + 1].y, acc1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {                // games as the row operand: acc[i] = game 4g + i, output n16
+            const f16x8 ah = __builtin_bit_cast(f16x8, aF[s][0]), al = __builtin_bit_cast(f16x8, aF[s][1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, hF[s][0]), bl = __builtin_bit_cast(f16x8, hF[s][1]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            acx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx0, 0, 0, 0);
+            acx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx1, 0, 0, 0);
         }
         if (n16 < 10) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = acc0[i] + acc1[i] + hb;
-                if (n16 == 0) sOut[4 * q + i][9] = tanhf(v);        // value; to_scalar is the identity (config.py:28)
-                else sOut[4 * q + i][n16 - 1] = v;
+                const float v = acc[i] + (acx0[i] + acx1[i]) * kUnsplit + hb;
+                if (n16 == 0) sOut[4 * g + i][9] = tanhf(v);        // value; to_scalar is the identity (config.py:28)
+                else sOut[4 * g + i][n16 - 1] = v;
             }
         }
     } else if (REWARD && wave == 1 && lane < 16) {
@@ -1710,6 +1742,24 @@ struct Packer {
             for (int n = 0; n < N; ++n) p[((size_t)(k / 8) * 128 + n) * 8 + (k % 8)] = W[(size_t)k * ldw + n];
         return add(p);
     }
+    // W[128][N] row-major (N <= 128) -> split-f16 fragments for v_mfma_f32_16x16x32_f16: 32-byte entry [s][n][g] holds
+    // the 8 h halfs, then the 8 l halfs, of k = 32s + 8g .. +7 of column n (missing columns zero).
+    size_t add_split16(const float* W, int N, int ldw) {
+        std::vector<_Float16> p((size_t)128 * 128 * 2, (_Float16)0.f);
+        for (int k = 0; k < 128; ++k)
+            for (int n = 0; n < N; ++n) {
+                const float w = W[(size_t)k * ldw + n];
+                const _Float16 h = (_Float16)w;
+                const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+                const int st = k / 32, g = (k % 32) / 8, i = k % 8;
+                const size_t e = (((size_t)st * 128 + n) * 4 + g) * 16;
+                p[e + i] = h;
+                p[e + 8 + i] = l;
+            }
+        std::vector<float> f((size_t)128 * 128);
+        memcpy(f.data(), p.data(), f.size() * sizeof(float));
+        return add(f);
+    }
     // W[128][128] row-major -> split-f16 MFMA fragments for v_mfma_f32_32x32x16_f16, the size of the f32 matrix:
     // 16-byte entry [j = 2t + plane][n][g] holds the 8 halfs k = 16t + 8g .. +7 of column n; plane 0 = h = f16(w),
     // plane 1 = l = f16((w - h) * 2048).  w ~= h + l/2048 to 22 mantissa bits.
@@ -1865,7 +1915,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         }
         off.push_back(first);                                          // 9
         off.push_back(pk.add(pred_conv_b, 128));                       // 10
-        off.push_back(pk.add_packed(pred_dense, 128, 128, 128));       // 11
+        off.push_back(pk.add_split16(pred_dense, 128, 128));           // 11
         off.push_back(pk.add(pred_dense_b, 128));                      // 12
         off.push_back(pk.add(pred_value, 128));                        // 13
         std::vector<float> polT(9 * 128);
@@ -1913,7 +1963,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         }
         net->ttt.job_first[4] = (int)desc.size() / 4;
         off.push_back(pk.add(desc));                                   // 16
-        off.push_back(pk.add_packed(headW.data(), 128, 16, 16));       // 17
+        off.push_back(pk.add_split16(headW.data(), 16, 16));           // 17
         off.push_back(pk.add(headB));                                  // 18
         for (int t = 0; t < 9; ++t) {
             const size_t o = pk.add_split_f16(dyn_conv + (size_t)t * 137 * 128, 128);
