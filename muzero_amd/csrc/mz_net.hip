@@ -1126,6 +1126,13 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
     const float4 db[2] = {*reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 4 * g),
                           *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 16 + 4 * g)};
     const float hb = w.pred_head_b[n16];
+    // the reward partials too (wave 1): requested now, summed under the first barrier instead of at the very end
+    float rp[9];
+    if (REWARD && wave == 1 && lane < 16) {
+        const int b = min(row0 + lane, B - 1);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) rp[c] = rpart[(size_t)b * 9 + c];
+    }
     float4 bF[2][4][2], hF[4][2];                    // [column block][k-step][h | l]
     {
         const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + ((size_t)(wave * 32 + n16) * 4 + g) * 2;
@@ -1173,6 +1180,12 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
         }
+    }
+    if (REWARD && wave == 1 && lane < 16) {
+        float rs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) rs += rp[c];
+        sOut[lane][10] = tanhf(rs + w.dyn_reward_b);
     }
     __syncthreads();
     {
@@ -1234,12 +1247,6 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
                 else sOut[4 * g + i][n16 - 1] = v;
             }
         }
-    } else if (REWARD && wave == 1 && lane < 16) {
-        const int b = min(row0 + lane, B - 1);
-        float rs = 0.f;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) rs += rpart[(size_t)b * 9 + c];
-        sOut[lane][10] = tanhf(rs + w.dyn_reward_b);
     }
     __syncthreads();
 }
