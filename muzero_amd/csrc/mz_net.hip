@@ -144,6 +144,7 @@ struct TttDev {
     const float* dyn_conv_h;    // the three GEMM operands of the job kernel again, as split-f16 fragments (pack_split_f16)
     const float* dyn_dense_h;
     const float* pred_conv_h;
+    const float* rep_dense_h;
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     float dyn_reward_b, pred_value_b;
@@ -908,28 +909,142 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     }
 }
 
-// f32 rows of 128 -> split images in place (the root hidden states of a native move).  One row per half wavefront:
-// every lane has its four floats before any lane writes.
-__global__ __launch_bounds__(kThreads) void split_rows_kernel(float* __restrict__ rows, long nrows) {
-    const long row = (long)blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
-    const int c4 = threadIdx.x & 31;
-    if (row >= nrows) return;
-    float* p = rows + row * 128;
-    const float4 v = *reinterpret_cast<const float4*>(p + c4 * 4);
-    f16x4 h, l;
-    const float x[4] = {v.x, v.y, v.z, v.w};
+// One 128 x 128 GEMM stage on split operands without the job kernel's pipelining: acc += sA[32][128] * W, weights in b
+// (split fragments), product transposed like mma_block_h.  Returns with the cross terms folded in.
+__device__ __forceinline__ void mma_tile_h_plain(const _Float16* sA, const BFrag& b, f32x16& acc, int lane) {
+    const _Float16* ap = sA + (lane & 31) * kLdH + 8 * (lane >> 5);
+    f32x16 acc2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        _Float16 hj, lj;
-        split_f16(x[j], hj, lj);
-        h[j] = hj;
-        l[j] = lj;
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    float4 ah = *reinterpret_cast<const float4*>(ap), al = *reinterpret_cast<const float4*>(ap + 128);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        float4 nh = ah, nl = al;
+        if (T + 1 < 8) {
+            nh = *reinterpret_cast<const float4*>(ap + (T + 1) * 16);
+            nl = *reinterpret_cast<const float4*>(ap + 128 + (T + 1) * 16);
+        }
+        const f16x8 xh = __builtin_bit_cast(f16x8, ah), xl = __builtin_bit_cast(f16x8, al);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * T]), bl = __builtin_bit_cast(f16x8, b.v[2 * T + 1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, xh, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, xh, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, xl, acc2, 0, 0, 0);
+        ah = nh;
+        al = nl;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    _Float16* q = reinterpret_cast<_Float16*>(p);
-    *reinterpret_cast<f16x4*>(q + c4 * 4) = h;
-    *reinterpret_cast<f16x4*>(q + 128 + c4 * 4) = l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
+}
+
+// Initial inference, split-f16: the job kernel's grid and jobs (32 games x a group of cells; descriptors of kind 1 and 2
+// are the cells' Dense and prediction stages, the taps are skipped).  Per cell: representation Conv2D 3x3 same 3 -> 128
+// relu on the VALU (K = 27, games/tictactoe.py:182), Dense 128 -> 128 relu = hidden[cell] (:184), and the cell's term
+// of the prediction conv (:201) accumulated over the job's cells: one partial per (game, job), so the head is the
+// recurrent one's.  SPLIT_IO: hidden leaves as split images (the workspace of a native move), else as f32.
+template <bool SPLIT_IO>
+__global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, int B, const float* __restrict__ observation,
+                                                                    float* __restrict__ out_hidden,
+                                                                    float* __restrict__ ppart) {
+    constexpr int ROWS = 32;
+    __shared__ __attribute__((aligned(16))) float sXF[ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
+    __shared__ float sObs[ROWS * 27];
+    _Float16* sX = reinterpret_cast<_Float16*>(sXF);
+    _Float16* sH = reinterpret_cast<_Float16*>(sHF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
+    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
+    for (int i = tid; i < ROWS * 27; i += kThreads) {
+        const int b = row0 + i / 27;
+        sObs[i] = b < B ? observation[(size_t)b * 27 + i % 27] : 0.f;
+    }
+    BFrag bd;
+    load_b(bd, w.rep_dense_h, lane, wave);           // the same Dense for every cell
+    const int lrow = lane & 31, lcol = wave * 32 + 4 * (lane >> 5);     // transposed accumulators, see mma_block_h
+    const bool lrow_ok = row0 + lrow < B;
+    const int c4 = tid & 31, r0 = tid >> 5;          // conv: columns 4 c4 .. +3 of rows r0 + 8 i
+    const float4 cb = *reinterpret_cast<const float4*>(w.rep_conv_b + 4 * c4);
+    float4 db[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) db[q] = *reinterpret_cast<const float4*>(w.rep_dense_b + lcol + 8 * q);
+    f32x16 accp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int d = 0; d < d1; ++d) {
+        const int4 D = w.job_desc[dbase + d];
+        const int kind = __builtin_amdgcn_readfirstlane(D.x & 7), cell = __builtin_amdgcn_readfirstlane(D.y);
+        if (kind != 1) continue;                     // one pass per cell
+        BFrag bp;
+        load_b(bp, w.pred_conv_h + (size_t)cell * 16384, lane, wave);
+        const int ci = cell / 3, cj = cell % 3;
+        float4 s[4] = {cb, cb, cb, cb};
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
+            if (ni < 0 || ni >= 3 || nj < 0 || nj >= 3) continue;
+            const float4* wt = reinterpret_cast<const float4*>(w.rep_conv + (size_t)t * 3 * 128) + c4;
+            const float4 w0 = wt[0], w1 = wt[32], w2 = wt[64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* o = sObs + (r0 + 8 * i) * 27 + (ni * 3 + nj) * 3;
+                const float o0 = o[0], o1 = o[1], o2 = o[2];
+                s[i].x = __builtin_fmaf(o2, w2.x, __builtin_fmaf(o1, w1.x, __builtin_fmaf(o0, w0.x, s[i].x)));
+                s[i].y = __builtin_fmaf(o2, w2.y, __builtin_fmaf(o1, w1.y, __builtin_fmaf(o0, w0.y, s[i].y)));
+                s[i].z = __builtin_fmaf(o2, w2.z, __builtin_fmaf(o1, w1.z, __builtin_fmaf(o0, w0.z, s[i].z)));
+                s[i].w = __builtin_fmaf(o2, w2.w, __builtin_fmaf(o1, w1.w, __builtin_fmaf(o0, w0.w, s[i].w)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x[4] = {fmaxf(s[i].x, 0.f), fmaxf(s[i].y, 0.f), fmaxf(s[i].z, 0.f), fmaxf(s[i].w, 0.f)};
+            uint2 h, l;
+            split4(x, h, l);
+            _Float16* row = sX + (r0 + 8 * i) * kLdH + 4 * c4;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
+        }
+        __syncthreads();                             // sX complete; the previous cell's readers of sH are done
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_tile_h_plain(sX, bd, acc, lane);
+        float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x[4] = {fmaxf(acc[4 * q] + db[q].x, 0.f), fmaxf(acc[4 * q + 1] + db[q].y, 0.f),
+                                fmaxf(acc[4 * q + 2] + db[q].z, 0.f), fmaxf(acc[4 * q + 3] + db[q].w, 0.f)};
+            uint2 h, l;
+            split4(x, h, l);
+            *reinterpret_cast<uint2*>(sH + lrow * kLdH + lcol + 8 * q) = h;
+            *reinterpret_cast<uint2*>(sH + lrow * kLdH + 128 + lcol + 8 * q) = l;
+            if (!SPLIT_IO && lrow_ok)
+                *reinterpret_cast<float4*>(ocell + (unsigned)lrow * 1152u + lcol + 8 * q) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+        __syncthreads();
+        if (SPLIT_IO) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + 8 * i;
+                if (row0 + r < B)
+                    *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + c4 * 4) =
+                        *reinterpret_cast<const float4*>(sH + r * kLdH + c4 * 8);
+            }
+        }
+        mma_tile_h_plain(sH, bp, accp, lane);
+    }
+    if (lrow_ok) {
+        float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(pjob + (unsigned)lrow * 1152u + lcol + 8 * q) =
+                make_float4(accp[4 * q], accp[4 * q + 1], accp[4 * q + 2], accp[4 * q + 3]);
+    }
 }
 
 // Diagnostic twin of ttt_job_kernel with in-kernel segment stamps (tools/trace_cell.py); never used by the product path.
@@ -1983,6 +2098,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             if (c == 0) first = o;
         }
         off.push_back(first);                                          // 21
+        off.push_back(pk.add_split_f16(rep_dense, 128));               // 22
     } else {
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
@@ -2070,6 +2186,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         t.dyn_conv_h = d + off[19];
         t.dyn_dense_h = d + off[20];
         t.pred_conv_h = d + off[21];
+        t.rep_dense_h = d + off[22];
     } else {
         CartDev& c = net->cart;
         c.rep_conv = d + off[0];
@@ -2161,8 +2278,8 @@ static int tile_rows(const mz_net* net, int batch) {
     return wg64 >= 512 ? 64 : 32;
 }
 
-int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
-                     float* out_logits, float* out_value_raw) {
+static int infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
+                         float* out_logits, float* out_value_raw, bool split_hidden) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
     net->hidden_split = false;   // a move starts here; a native move that failed half way may have left it set
@@ -2175,16 +2292,31 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
-        if (rows == 64)
-            ttt_cell_kernel<true, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
-                                                                  out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
-        else
-            ttt_cell_kernel<true, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
-                                                                  out_hidden, net->ppart, net->rpart, cell_order(), net->trace);
-        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
-        ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                          out_value, out_logits, out_value_raw);
+        if (job_f32()) {
+            if (rows == 64)
+                ttt_cell_kernel<true, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
+                                                                      out_hidden, net->ppart, net->rpart, cell_order(),
+                                                                      net->trace);
+            else
+                ttt_cell_kernel<true, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
+                                                                      out_hidden, net->ppart, net->rpart, cell_order(),
+                                                                      net->trace);
+            if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+            ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                              out_value, out_logits, out_value_raw);
+        } else {
+            const int nrb32 = (batch + 31) / 32;
+            if (split_hidden)
+                ttt_initial_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
+                                                                                       out_hidden, net->ppart);
+            else
+                ttt_initial_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
+                                                                                        out_hidden, net->ppart);
+            if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+            ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                              out_value, out_logits, out_value_raw);
+        }
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<true><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
                                                                          out_hidden, nullptr, out_value, out_logits,
@@ -2198,6 +2330,11 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
                                                               out_hidden, nullptr, out_value, out_logits, out_value_raw);
     }
     return launch_status("initial inference");
+}
+
+int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
+                     float* out_logits, float* out_value_raw) {
+    return infer_initial(net, batch, observation, out_hidden, out_value, out_logits, out_value_raw, false);
 }
 
 int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
@@ -2262,17 +2399,14 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
     return launch_status("recurrent inference");
 }
 
-// Internal to the library (mz_pool_internal.h): a native move owns its hidden workspace, so the TicTacToe job kernel keeps
-// it as split images.  begin: converts the root rows written by the initial inference (block 0, T x H floats) in place.
-__attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, float* hidden_block0, int batch) {
-    if (net->kind != MZ_NET_TICTACTOE || job_f32()) return MZ_OK;
-    MZ_HIP(hipSetDevice(net->device));
-    const long nrows = (long)batch * 9;
-    split_rows_kernel<<<(unsigned)((nrows + kThreads / 32 - 1) / (kThreads / 32)), kThreads, 0, net->stream>>>(hidden_block0, nrows);
-    int s = launch_status("split_rows_kernel");
-    if (s != MZ_OK) return s;
-    net->hidden_split = true;
-    return MZ_OK;
+// Internal to the library (mz_pool_internal.h): the initial inference of a native move.  The move owns its hidden
+// workspace, so the TicTacToe kernels keep it as split images from the root rows on (until mz_net_end_move).
+__attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, int batch, const float* observation,
+                                                            float* hidden_block0, float* out_value, float* out_logits) {
+    const bool split = net != nullptr && net->kind == MZ_NET_TICTACTOE && !job_f32();
+    const int s = infer_initial(net, batch, observation, hidden_block0, out_value, out_logits, nullptr, split);
+    if (s == MZ_OK && batch > 0) net->hidden_split = split;
+    return s;
 }
 __attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->hidden_split = false; }
 

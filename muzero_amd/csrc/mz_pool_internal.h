@@ -22,8 +22,10 @@ struct mz_pool {
 int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block);
 void mz_pool_commit_backprop(mz_pool* pool, bool with_select);
 
-// A native move (mz_search_move) brackets its simulations with these: between them the network may keep the move's hidden
-// workspace in an internal format (mz_net.hip).  hidden_block0: the root hidden states just written by mz_infer_initial.
+// A native move (mz_search_move) brackets its inferences with these: begin = the initial inference (mz_infer_initial's
+// arguments; hidden_block0 receives the root hidden states), after which and until end the network keeps the move's
+// hidden workspace in an internal format (mz_net.hip).
 struct mz_net;
-extern "C" int mz_net_begin_move(mz_net* net, float* hidden_block0, int batch);
+extern "C" int mz_net_begin_move(mz_net* net, int batch, const float* observation, float* hidden_block0, float* out_value,
+                                 float* out_logits);
 extern "C" void mz_net_end_move(mz_net* net);

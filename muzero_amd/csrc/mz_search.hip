@@ -21,8 +21,8 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         if (s_ != MZ_OK) return s_; \
     } while (0)
     MZ_TRY_(mz_pool_reset(pool));
-    MZ_TRY_(mz_infer_initial(net, T, io->observation, io->hidden, io->value, io->logits, nullptr));
-    MZ_TRY_(mz_net_begin_move(net, io->hidden, T));      // from here to the end the hidden workspace is the network's
+    // initial inference; from here to the end the hidden workspace is the network's
+    MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
     MZ_TRY_(mz_expand_roots_logits(pool, io->logits, io->legal, io->n_legal));
     MZ_TRY_(mz_add_root_noise(pool, io->noise, io->noise_frac));
     MZ_TRY_(mz_select(pool, io->parent_block, io->action));
