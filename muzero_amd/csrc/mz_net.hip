@@ -145,6 +145,9 @@ struct TttDev {
     const float* dyn_dense_h;
     const float* pred_conv_h;
     const float* rep_dense_h;
+    const float* dyn_conv_s;    // and as fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16w): ttt_job_kernel_w
+    const float* dyn_dense_s;
+    const float* pred_conv_s;
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     float dyn_reward_b, pred_value_b;
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
 // Operand images: weights pre-split on the host (Packer::add_split_f16, same bytes and the same register ring as the
 // f32 fragments); activation tiles in LDS as [row][128 h | 128 l] halfs on the f32 tile's 528-byte row stride, so the
 // fragment reads keep the f32 kernel's conflict-free geometry.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int kLdH = 2 * kLd;        // tile row stride in halfs
@@ -909,6 +913,296 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
     }
 }
 
+// ---- the job kernel on 64-row tiles
+// Same jobs, stages and outputs as ttt_job_kernel_h, for 64 games per 512-thread workgroup (one per CU).  The 32-row
+// kernel is bound by the bytes a CU pulls through its vector-memory path (64 KB of weight fragments per stage and 32
+// rows); here a workgroup still loads every fragment once, but for 64 rows: wave v owns output columns 16v .. 16v+15
+// of all 64 rows, as four 16-row blocks on v_mfma_f32_16x16x32_f16 (weights as the row operand, so a lane holds four
+// consecutive columns of one game per block).  A lane's operand for k-step s is the 8 halfs k = 32s + 8 (lane/16) .. +7
+// of column / game lane % 16: weights packed by Packer::add_split16w, activations as [row][128 h | 128 l] images in LDS.
+constexpr int kThreadsW = 512;
+constexpr int kLdW = 272;          // tile row stride in halfs: 136 dwords, the stride at which the sixteen-lane groups of a
+                                   // ds_read_b128 (row = lane % 16, 16-byte chunk = lane / 16) fall on 64 distinct banks
+struct BFragW {
+    float4 v[8];                   // [k-step][h | l] of this wave's 16 columns
+};
+__device__ __forceinline__ void load_bw(BFragW& b, const float* __restrict__ Ws, int lane, int wave) {
+    const float4* wp = reinterpret_cast<const float4*>(Ws) + wave * 64 + lane;       // Packer::add_split16w
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b.v[j] = wp[j * 512];
+}
+
+template <bool SPLIT_IO>
+__global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B, const float* __restrict__ in_base,
+                                                                 const int* __restrict__ parent_block, long block_stride,
+                                                                 const int* __restrict__ action,
+                                                                 float* __restrict__ out_hidden, float* __restrict__ ppart,
+                                                                 float* __restrict__ rpart) {
+    constexpr int ROWS = 64;
+    __shared__ __attribute__((aligned(16))) _Float16 sTileW[2][ROWS * kLdW];
+    __shared__ __attribute__((aligned(16))) _Float16 sX[ROWS * kLdW];
+    __shared__ __attribute__((aligned(16))) _Float16 sH[ROWS * kLdW];
+    __shared__ long sRowOff[ROWS];
+    __shared__ int sAct[ROWS];
+    __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // as in ttt_job_kernel_h
+    __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
+    auto tile = [&](int b) { return sTileW[b]; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int job = bi & 3, rb = (bi >> 2) * 8 + xl;       // the four jobs of a row block share an XCD (its L2)
+    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
+    const int n16 = lane & 15, g = lane >> 4;
+    const int lcol = wave * 16 + 4 * g;              // this lane's four columns: lcol .. lcol + 3
+    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_s) + wave * 64 + lane;
+
+    if (tid < 128) sBias[10 * 128 + tid] = w.dyn_dense_b[tid];
+    BFragW bw;
+    typedef int __attribute__((ext_vector_type(4))) Desc;      // .x kind | flags, .y cell, .z tap, .w source cell
+    typedef const __attribute__((address_space(4))) Desc* DescPtr;
+    const DescPtr desc = (DescPtr)w.job_desc + dbase;
+    const Desc D0 = desc[0];
+    load_bw(bw, w.dyn_conv_s + (size_t)D0.z * 16384, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            const int pb = parent_block ? parent_block[b] : 0;
+            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
+            a = action[b];
+            if (a < 0 || a > 8) a = 0;
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    const float* sptr[4];
+    unsigned svalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
+        const long off = sRowOff[r];
+        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
+        if (off >= 0) svalid |= 1u << i;
+    }
+    float4 stg[4];
+    auto commit = [&](_Float16* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
+            const bool ok = (svalid >> i) & 1u;
+            if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
+                *reinterpret_cast<float4*>(buf + r * kLdW + c4 * 8) = ok ? stg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
+                uint2 h, l;
+                split4(v, h, l);
+                *reinterpret_cast<uint2*>(buf + r * kLdW + c4 * 4) = h;
+                *reinterpret_cast<uint2*>(buf + r * kLdW + 128 + c4 * 4) = l;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
+    commit(tile(0));
+    {   // stage 1's tile, if it gathers one, is on its way while stage 0 starts
+        const Desc D1 = desc[d1 > 1 ? 1 : 0];
+        const int src1 = (d1 > 1 && (D1.x & 7) == 0) ? D1.w * 128 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src1);
+    }
+    __syncthreads();
+
+    // rows with an output (game < B and a parent): one bit per row; this lane's rows are n16 + 16 m, m = 0..3
+    const unsigned long long rowmask = __ballot(sRowOff[lane] >= 0);
+    int lact[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) lact[m] = sAct[16 * m + n16];
+    f32x4 acc[4], accp[4];                           // accp: prediction-conv partial, summed over the job's cells
+#pragma unroll
+    for (int m = 0; m < 4; ++m) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    Desc Dc = D0, Dn = desc[d1 > 1 ? 1 : 0], Dn2 = desc[d1 > 2 ? 2 : 0];
+#pragma unroll 1
+    for (int d = 0; d < d1; ++d) {
+        const bool has_next = d + 1 < d1;
+        const bool gather2 = d + 2 < d1 && (Dn2.x & 7) == 0;
+        const int nsrc2 = Dn2.w;
+        const int kind = Dc.x & 7, cell = Dc.y;
+        const int nkind = has_next ? Dn.x & 7 : kind;
+        const bool first_tap = (Dc.x & 8) != 0, last_tap = (Dc.x & 16) != 0;
+        const int ntap = has_next ? Dn.z : Dc.z, ncell = has_next ? Dn.y : Dc.y;
+        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
+        const float* wn = nkind == 0 ? w.dyn_conv_s + (size_t)ntap * 16384
+                        : nkind == 1 ? w.dyn_dense_s : w.pred_conv_s + (size_t)ncell * 16384;
+        const float4* wnext = wlane + (wn - w.dyn_conv_s) / 4;
+        const bool gather = has_next && nkind == 0;
+        const _Float16* sA = kind == 0 ? tile(buf) : kind == 1 ? sX : sH;
+        if (kind == 1 || first_tap) {
+            asm volatile("");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float bt[3];
+        if (kind == 0 && first_tap) {
+            // first tap of a cell: its bias table for all nine actions and its reward weights, requested ahead of this
+            // stage's weight loads and parked in LDS at the end of the stage (see ttt_job_kernel_h)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int idx = tid + kThreadsW * i;
+                bt[i] = idx < 9 * 128    ? w.dyn_actbias[((idx >> 7) * 9 + cell) * 128 + (idx & 127)]
+                        : idx < 10 * 128 ? w.dyn_reward_w[cell * 128 + (idx & 127)]
+                                         : 0.f;
+            }
+        }
+        if (kind == 2) {
+            asm volatile("");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = accp[m];
+        }
+        {   // ---- the stage's MFMAs: 4 k-steps x 4 row blocks x 3
+            const _Float16* ap = sA + n16 * kLdW + 8 * g;
+            f32x4 acx[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 af[2][4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+                af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the priming reads come first
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s + 1 < 4) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
+                        af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+                    }
+                }
+                const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, af[s & 1][m][0]), al = __builtin_bit_cast(f16x8, af[s & 1][m][1]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[m], 0, 0, 0);
+                    acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[m], 0, 0, 0);
+                    acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[m], 0, 0, 0);
+                }
+                bw.v[2 * s] = wnext[(2 * s) * 512];  // in-place ring: the next stage's fragments
+                bw.v[2 * s + 1] = wnext[(2 * s + 1) * 512];
+                // pin the interleave: the next k-step's eight fragment reads, this k-step's twelve MFMAs, its VMEM reads
+                if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (s == 1 && gather) commit(tile(buf ^ 1));     // the tile requested during the previous stage
+                if (s == 2) {                                    // the tile two stages ahead
+                    const int src = gather2 ? nsrc2 * 128 : 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on
+        if (kind == 2) {
+            asm volatile("");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) accp[m] = acc[m];
+        }
+        if (kind == 0) {
+            if (first_tap) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int idx = tid + kThreadsW * i;
+                    if (idx < 10 * 128) sBias[idx] = bt[i];
+                }
+            }
+            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sBias + lact[m] * 128 + lcol);
+                    const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
+                                        fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
+                    uint2 h, l;
+                    split4(v, h, l);
+                    _Float16* row = sX + (16 * m + n16) * kLdW + lcol;
+                    *reinterpret_cast<uint2*>(row) = h;
+                    *reinterpret_cast<uint2*>(row + 128) = l;
+                }
+            }
+            __syncthreads();
+            if (gather) buf ^= 1;
+        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
+            {
+                const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol);
+                const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
+                                        fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
+                    // reward head (games/tictactoe.py:193-195): this lane's four columns, then the wave's sixteen
+                    float rdot = __builtin_fmaf(v[3], rw.w, __builtin_fmaf(v[2], rw.z, __builtin_fmaf(v[1], rw.y, v[0] * rw.x)));
+                    rdot += __shfl_xor(rdot, 16);
+                    rdot += __shfl_xor(rdot, 32);
+                    if (g == 0) sRew[wave * ROWS + 16 * m + n16] = rdot;
+                    uint2 h, l;
+                    split4(v, h, l);
+                    _Float16* row = sH + (16 * m + n16) * kLdW + lcol;
+                    *reinterpret_cast<uint2*>(row) = h;
+                    *reinterpret_cast<uint2*>(row + 128) = l;
+                    if (!SPLIT_IO && ((rowmask >> (16 * m + n16)) & 1ull))                      // f32, unsplit
+                        *reinterpret_cast<float4*>(ocell + (unsigned)(16 * m + n16) * 1152u + lcol) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
+            if (SPLIT_IO) {                        // sH is the row image the workspace wants: copied out 16 bytes a thread
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
+                    if ((svalid >> i) & 1u)
+                        *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + c4 * 4) =
+                            *reinterpret_cast<const float4*>(sH + r * kLdW + c4 * 8);
+                }
+            }
+            if (tid < ROWS) {
+                int grow = row0 + tid;
+                asm volatile("" : "+v"(grow));
+                if ((rowmask >> tid) & 1ull) {
+                    float rs = 0.f;
+#pragma unroll
+                    for (int v8 = 0; v8 < 8; ++v8) rs += sRew[v8 * ROWS + tid];
+                    rpart[(size_t)grow * 9 + cell] = rs;
+                }
+            }
+        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
+            if (!has_next) {      // end of the job: one partial per (game, job)
+                int prow = row0;
+                asm volatile("" : "+s"(prow));
+                float* const pjob = ppart + (size_t)prow * 1152 + job * 128;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if ((rowmask >> (16 * m + n16)) & 1ull)
+                        *reinterpret_cast<float4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) =
+                            make_float4(accp[m][0], accp[m][1], accp[m][2], accp[m][3]);
+            }
+            __syncthreads();
+            if (gather) buf ^= 1;
+        }
+        Dc = Dn;
+        Dn = Dn2;
+        Dn2 = Dn3;
+    }
+}
+
 // One 128 x 128 GEMM stage on split operands without the job kernel's pipelining: acc += sA[32][128] * W, weights in b
 // (split fragments), product transposed like mma_block_h.  Returns with the cross terms folded in.
 __device__ __forceinline__ void mma_tile_h_plain(const _Float16* sA, const BFrag& b, f32x16& acc, int lane) {
@@ -1228,8 +1522,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, i
 // with the weights as the row operand: a lane then holds four consecutive columns of one game, split and stored 8 bytes
 // at a time.  The ten head outputs are one more 16-column block (wave 0).
 // Results: sOut[game][0..8] logits, [9] value, [10] reward.  Ends with a barrier.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
 template <int NP, bool REWARD>
 __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, const float* __restrict__ ppart,
                                            const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12]) {
@@ -1882,6 +2174,24 @@ struct Packer {
         memcpy(f.data(), p.data(), f.size() * sizeof(float));
         return add(f);
     }
+    // The same fragments in the order ttt_job_kernel_w loads them: 16-byte entry [s][plane][wave][lane], wave = n / 16,
+    // lane = 16 g + n % 16, holds the 8 halfs k = 32s + 8g .. +7 of column n (plane 0 = h, 1 = l): one load instruction of
+    // a wavefront reads 1 KiB of consecutive bytes.
+    size_t add_split16w(const float* W, int ldw) {
+        std::vector<_Float16> p((size_t)128 * 128 * 2);
+        for (int k = 0; k < 128; ++k)
+            for (int n = 0; n < 128; ++n) {
+                const float w = W[(size_t)k * ldw + n];
+                const _Float16 h = (_Float16)w;
+                const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+                const int st = k / 32, g = (k % 32) / 8, i = k % 8, lane = 16 * g + n % 16, wave = n / 16;
+                p[((((size_t)st * 2 + 0) * 8 + wave) * 64 + lane) * 8 + i] = h;
+                p[((((size_t)st * 2 + 1) * 8 + wave) * 64 + lane) * 8 + i] = l;
+            }
+        std::vector<float> f((size_t)128 * 128);
+        memcpy(f.data(), p.data(), f.size() * sizeof(float));
+        return add(f);
+    }
     // W[128][128] row-major -> split-f16 MFMA fragments for v_mfma_f32_32x32x16_f16, the size of the f32 matrix:
     // 16-byte entry [j = 2t + plane][n][g] holds the 8 halfs k = 16t + 8g .. +7 of column n; plane 0 = h = f16(w),
     // plane 1 = l = f16((w - h) * 2048).  w ~= h + l/2048 to 22 mantissa bits.
@@ -1942,6 +2252,12 @@ int ensure_scratch(mz_net* net, int batch) {
 // MZ_JOB_F32=1: the f32-MFMA job kernel instead of the split-f16 one (comparison runs)
 bool job_f32() {
     static const bool v = getenv("MZ_JOB_F32") != nullptr;
+    return v;
+}
+
+// MZ_JOB_ROWS32=1: the 32-row split-f16 job kernel instead of the 64-row one (comparison runs)
+bool job_rows32() {
+    static const bool v = getenv("MZ_JOB_ROWS32") != nullptr;
     return v;
 }
 
@@ -2099,6 +2415,17 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         }
         off.push_back(first);                                          // 21
         off.push_back(pk.add_split_f16(rep_dense, 128));               // 22
+        for (int t = 0; t < 9; ++t) {
+            const size_t o = pk.add_split16w(dyn_conv + (size_t)t * 137 * 128, 128);
+            if (t == 0) first = o;
+        }
+        off.push_back(first);                                          // 23
+        off.push_back(pk.add_split16w(dyn_dense, 128));                // 24
+        for (int c = 0; c < 9; ++c) {
+            const size_t o = pk.add_split16w(pred_conv + (size_t)c * 128 * 128, 128);
+            if (c == 0) first = o;
+        }
+        off.push_back(first);                                          // 25
     } else {
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
@@ -2187,6 +2514,9 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         t.dyn_dense_h = d + off[20];
         t.pred_conv_h = d + off[21];
         t.rep_dense_h = d + off[22];
+        t.dyn_conv_s = d + off[23];
+        t.dyn_dense_s = d + off[24];
+        t.pred_conv_s = d + off[25];
     } else {
         CartDev& c = net->cart;
         c.rep_conv = d + off[0];
@@ -2364,10 +2694,13 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                 ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
                                                                             action, out_hidden, net->ppart, net->rpart,
                                                                             nullptr);
-            else
+            else if (job_rows32())
                 ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base,
                                                                                      parent_block, bs, action, out_hidden,
                                                                                      net->ppart, net->rpart);
+            else
+                ttt_job_kernel_w<false><<<32 * (((batch + 63) / 64 + 7) / 8), kThreadsW, 0, st>>>(
+                    net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart);
         } else if (rows == 64)
             ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
                                                                    out_hidden, net->ppart, net->rpart, cell_order(),
@@ -2441,14 +2774,26 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
         ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
                                                                     (long)block_stride, action, out_hidden, net->ppart,
                                                                     net->rpart, nullptr);
-    else if (net->hidden_split)
-        ttt_job_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                            (long)block_stride, action, out_hidden,
-                                                                            net->ppart, net->rpart);
-    else
-        ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                             (long)block_stride, action, out_hidden,
-                                                                             net->ppart, net->rpart);
+    else if (job_rows32()) {
+        if (net->hidden_split)
+            ttt_job_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                                (long)block_stride, action, out_hidden,
+                                                                                net->ppart, net->rpart);
+        else
+            ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base,
+                                                                                 parent_block, (long)block_stride, action,
+                                                                                 out_hidden, net->ppart, net->rpart);
+    } else {
+        const int gridw = 32 * (((batch + 63) / 64 + 7) / 8);
+        if (net->hidden_split)
+            ttt_job_kernel_w<true><<<gridw, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                (long)block_stride, action, out_hidden, net->ppart,
+                                                                net->rpart);
+        else
+            ttt_job_kernel_w<false><<<gridw, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                 (long)block_stride, action, out_hidden, net->ppart,
+                                                                 net->rpart);
+    }
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)
