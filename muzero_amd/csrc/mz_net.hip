@@ -145,7 +145,7 @@ struct TttDev {
     const float* dyn_dense_h;
     const float* pred_conv_h;
     const float* rep_dense_h;
-    const float* dyn_conv_s;    // and as fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16w): ttt_job_kernel_w
+    const float* dyn_conv_s;    // and as fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16): ttt_job_kernel_w
     const float* dyn_dense_s;
     const float* pred_conv_s;
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B,
 // rows); here a workgroup still loads every fragment once, but for 64 rows: wave v owns output columns 16v .. 16v+15
 // of all 64 rows, as four 16-row blocks on v_mfma_f32_16x16x32_f16 (weights as the row operand, so a lane holds four
 // consecutive columns of one game per block).  A lane's operand for k-step s is the 8 halfs k = 32s + 8 (lane/16) .. +7
-// of column / game lane % 16: weights packed by Packer::add_split16w, activations as [row][128 h | 128 l] images in LDS.
+// of column / game lane % 16: weights packed by Packer::add_split16, activations as [row][128 h | 128 l] images in LDS.
 constexpr int kThreadsW = 512;
 constexpr int kLdW = 272;          // tile row stride in halfs: 136 dwords, the stride at which the sixteen-lane groups of a
                                    // ds_read_b128 (row = lane % 16, 16-byte chunk = lane / 16) fall on 64 distinct banks
@@ -927,7 +927,7 @@ struct BFragW {
     float4 v[8];                   // [k-step][h | l] of this wave's 16 columns
 };
 __device__ __forceinline__ void load_bw(BFragW& b, const float* __restrict__ Ws, int lane, int wave) {
-    const float4* wp = reinterpret_cast<const float4*>(Ws) + wave * 64 + lane;       // Packer::add_split16w
+    const float4* wp = reinterpret_cast<const float4*>(Ws) + wave * 64 + lane;       // Packer::add_split16
 #pragma unroll
     for (int j = 0; j < 8; ++j) b.v[j] = wp[j * 512];
 }
@@ -1026,6 +1026,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
     for (int m = 0; m < 4; ++m) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     Desc Dc = D0, Dn = desc[d1 > 1 ? 1 : 0], Dn2 = desc[d1 > 2 ? 2 : 0];
+    MZ_TRACE_DECL;
+    MZ_TRACE_NW(0);                                  // prologue
 #pragma unroll 1
     for (int d = 0; d < d1; ++d) {
         const bool has_next = d + 1 < d1;
@@ -1063,6 +1065,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = accp[m];
         }
+        MZ_TRACE_NW(1);                              // stage set-up
         {   // ---- the stage's MFMAs: 4 k-steps x 4 row blocks x 3
             const _Float16* ap = sA + n16 * kLdW + 8 * g;
             f32x4 acx[4];
@@ -1109,6 +1112,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
         }
+        MZ_TRACE_NW(2);                              // MFMA section
         __builtin_amdgcn_sched_barrier(0);
         const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on
         if (kind == 2) {
@@ -1137,7 +1141,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     *reinterpret_cast<uint2*>(row + 128) = l;
                 }
             }
+            MZ_TRACE_NW(3);                          // epilogue
             __syncthreads();
+            MZ_TRACE_NW(4);                          // barrier
             if (gather) buf ^= 1;
         } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
@@ -1163,7 +1169,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                             make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+            MZ_TRACE_NW(3);
             __syncthreads();
+            MZ_TRACE_NW(4);
             if (SPLIT_IO) {                        // sH is the row image the workspace wants: copied out 16 bytes a thread
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1194,9 +1202,12 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                         *reinterpret_cast<float4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) =
                             make_float4(accp[m][0], accp[m][1], accp[m][2], accp[m][3]);
             }
+            MZ_TRACE_NW(3);
             __syncthreads();
+            MZ_TRACE_NW(4);
             if (gather) buf ^= 1;
         }
+        MZ_TRACE_NW(5);                              // after the barrier
         Dc = Dn;
         Dn = Dn2;
         Dn2 = Dn3;
@@ -1542,13 +1553,13 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
     }
     float4 bF[2][4][2], hF[4][2];                    // [column block][k-step][h | l]
     {
-        const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + ((size_t)(wave * 32 + n16) * 4 + g) * 2;
+        const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + wave * 128 + lane;   // column block 2 wave + c
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                bF[c][s][0] = wp[s * 1024 + c * 128];
-                bF[c][s][1] = wp[s * 1024 + c * 128 + 1];
+                bF[c][s][0] = wp[(2 * s) * 512 + c * 64];
+                bF[c][s][1] = wp[(2 * s + 1) * 512 + c * 64];
             }
     }
     {   // every load of the tile is issued before the first use
@@ -1563,11 +1574,11 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             for (int c = 0; c < NP; ++c) v[i][c] = pp[c * 32];
         }
         if (wave == 0) {
-            const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + ((size_t)n16 * 4 + g) * 2;
+            const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + lane;                 // column block 0
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                hF[s][0] = hp[s * 1024];
-                hF[s][1] = hp[s * 1024 + 1];
+                hF[s][0] = hp[(2 * s) * 512];
+                hF[s][1] = hp[(2 * s + 1) * 512];
             }
         }
 #pragma unroll
@@ -2156,8 +2167,9 @@ struct Packer {
             for (int n = 0; n < N; ++n) p[((size_t)(k / 8) * 128 + n) * 8 + (k % 8)] = W[(size_t)k * ldw + n];
         return add(p);
     }
-    // W[128][N] row-major (N <= 128) -> split-f16 fragments for v_mfma_f32_16x16x32_f16: 32-byte entry [s][n][g] holds
-    // the 8 h halfs, then the 8 l halfs, of k = 32s + 8g .. +7 of column n (missing columns zero).
+    // W[128][N] row-major (N <= 128) -> split-f16 fragments for v_mfma_f32_16x16x32_f16 in the order ttt_head16 loads
+    // them: 16-byte entry [s][plane][block = n / 16][lane = 16 g + n % 16] holds the 8 halfs k = 32s + 8g .. +7 of column
+    // n (plane 0 = h, 1 = l; missing columns zero): one load instruction of a wavefront reads 1 KiB of consecutive bytes.
     size_t add_split16(const float* W, int N, int ldw) {
         std::vector<_Float16> p((size_t)128 * 128 * 2, (_Float16)0.f);
         for (int k = 0; k < 128; ++k)
@@ -2165,28 +2177,9 @@ struct Packer {
                 const float w = W[(size_t)k * ldw + n];
                 const _Float16 h = (_Float16)w;
                 const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
-                const int st = k / 32, g = (k % 32) / 8, i = k % 8;
-                const size_t e = (((size_t)st * 128 + n) * 4 + g) * 16;
-                p[e + i] = h;
-                p[e + 8 + i] = l;
-            }
-        std::vector<float> f((size_t)128 * 128);
-        memcpy(f.data(), p.data(), f.size() * sizeof(float));
-        return add(f);
-    }
-    // The same fragments in the order ttt_job_kernel_w loads them: 16-byte entry [s][plane][wave][lane], wave = n / 16,
-    // lane = 16 g + n % 16, holds the 8 halfs k = 32s + 8g .. +7 of column n (plane 0 = h, 1 = l): one load instruction of
-    // a wavefront reads 1 KiB of consecutive bytes.
-    size_t add_split16w(const float* W, int ldw) {
-        std::vector<_Float16> p((size_t)128 * 128 * 2);
-        for (int k = 0; k < 128; ++k)
-            for (int n = 0; n < 128; ++n) {
-                const float w = W[(size_t)k * ldw + n];
-                const _Float16 h = (_Float16)w;
-                const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
-                const int st = k / 32, g = (k % 32) / 8, i = k % 8, lane = 16 * g + n % 16, wave = n / 16;
-                p[((((size_t)st * 2 + 0) * 8 + wave) * 64 + lane) * 8 + i] = h;
-                p[((((size_t)st * 2 + 1) * 8 + wave) * 64 + lane) * 8 + i] = l;
+                const int st = k / 32, g = (k % 32) / 8, i = k % 8, lane = 16 * g + n % 16, blk = n / 16;
+                p[((((size_t)st * 2 + 0) * 8 + blk) * 64 + lane) * 8 + i] = h;
+                p[((((size_t)st * 2 + 1) * 8 + blk) * 64 + lane) * 8 + i] = l;
             }
         std::vector<float> f((size_t)128 * 128);
         memcpy(f.data(), p.data(), f.size() * sizeof(float));
@@ -2416,13 +2409,13 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         off.push_back(first);                                          // 21
         off.push_back(pk.add_split_f16(rep_dense, 128));               // 22
         for (int t = 0; t < 9; ++t) {
-            const size_t o = pk.add_split16w(dyn_conv + (size_t)t * 137 * 128, 128);
+            const size_t o = pk.add_split16(dyn_conv + (size_t)t * 137 * 128, 128, 128);
             if (t == 0) first = o;
         }
         off.push_back(first);                                          // 23
-        off.push_back(pk.add_split16w(dyn_dense, 128));                // 24
+        off.push_back(pk.add_split16(dyn_dense, 128, 128));               // 24
         for (int c = 0; c < 9; ++c) {
-            const size_t o = pk.add_split16w(pred_conv + (size_t)c * 128 * 128, 128);
+            const size_t o = pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128);
             if (c == 0) first = o;
         }
         off.push_back(first);                                          // 25
