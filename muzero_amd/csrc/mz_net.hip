@@ -155,66 +155,30 @@ struct TttDev {
 
 __constant__ int kCellOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // heaviest (9 taps) first, corners (4 taps) last
 
-// Kernel A.  grid = 9 * ceil(B / (32*MT)); block = 256.
-template <bool INITIAL, int MT>
-__global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, const float* __restrict__ in_base,
-                                                            const int* __restrict__ parent_block, long block_stride,
-                                                            const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                            float* __restrict__ ppart, float* __restrict__ rpart,
-                                                            int order, long long* __restrict__ trace) {
+// Initial inference on f32 MFMAs (MZ_JOB_F32 comparison path; the product path is ttt_initial_kernel_h): one workgroup
+// per (cell, 32*MT games).  grid = 9 * ceil(B / (32*MT)); block = 256.
+template <int MT>
+__global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, const float* __restrict__ observation,
+                                                            float* __restrict__ out_hidden, float* __restrict__ ppart) {
     constexpr int ROWS = 32 * MT;
-    constexpr int NSTG = MT * 4;                     // float4 staging loads per thread per tile
-    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
-    __shared__ long sRowOff[ROWS];                   // element offset of the row's input, -1 = skip
-    __shared__ int sAct[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
-    const int cell = order == 0 ? kCellOrder[blockIdx.x / nrb] : (int)(blockIdx.x % 9);
-    const int row0 = (order == 0 ? blockIdx.x % nrb : blockIdx.x / 9) * ROWS;
+    const int cell = kCellOrder[blockIdx.x / nrb];
+    const int row0 = (blockIdx.x % nrb) * ROWS;
     const int ci = cell / 3, cj = cell % 3;
 
     BFrag bcur, bnext;
-    unsigned tapmask = 0;                            // bit t set <=> tap t has an in-board source cell (uniform)
-    if (INITIAL) {
-        load_b(bcur, w.rep_dense_p, lane, wave);
-    } else {
-        for (int t = 0; t < 9; ++t) {
-            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
-            if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) tapmask |= 1u << t;
-        }
-        load_b(bcur, w.dyn_conv_p + (size_t)(__ffs(tapmask) - 1) * 16384, lane, wave);
-    }
-
-    if (tid < ROWS) {
-        const int b = row0 + tid;
-        long off = -1;
-        int a = 0;
-        if (b < B) {
-            if (INITIAL) {
-                off = (long)b * 27;
-            } else {
-                const int pb = parent_block ? parent_block[b] : 0;
-                if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-                a = action[b];
-                if (a < 0 || a > 8) a = 0;
-            }
-        }
-        sRowOff[tid] = off;
-        sAct[tid] = a;
-    }
-    __syncthreads();
-
+    load_b(bcur, w.rep_dense_p, lane, wave);
     f32x16 acc[MT];
     float* sX = sBuf[0];
     float* sH = sBuf[1];
-
-    if (INITIAL) {
+    {
         // representation Conv2D 3x3 same, 3 -> 128, relu (games/tictactoe.py:182): K = 27, done on the VALU
         float* sObs = sBuf[1];           // [ROWS][27]
         for (int i = tid; i < ROWS * 27; i += kThreads) {
-            const int r = i / 27;
-            sObs[i] = sRowOff[r] >= 0 ? in_base[sRowOff[r] + (i % 27)] : 0.f;
+            const int b = row0 + i / 27;
+            sObs[i] = b < B ? observation[(size_t)b * 27 + (i % 27)] : 0.f;
         }
         __syncthreads();
         const int n = tid & 127;
@@ -241,74 +205,14 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
         }
         load_b(bnext, w.pred_conv_p + (size_t)cell * 16384, lane, wave);
         __syncthreads();
-    } else {
-        // dynamics Conv2D 3x3 same over [hidden(128) | one-hot action(9)] (games/tictactoe.py:189):
-        // sum over valid neighbour cells of hidden[cell'] @ W[tap][0:128]; the action planes are a bias.
-        // Per-thread gather addresses of the activation tile, resolved once (branch-free loads afterwards).
-        const float* sptr[NSTG];
-        unsigned svalid = 0;
-#pragma unroll
-        for (int i = 0; i < NSTG; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            const long off = sRowOff[r];
-            sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
-            if (off >= 0) svalid |= 1u << i;
-        }
-        float4 stg[NSTG];
-        auto issue = [&](int t) {
-            const int src = ((ci + t / 3 - 1) * 3 + (cj + t % 3 - 1)) * 128;
-#pragma unroll
-            for (int i = 0; i < NSTG; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src);
-        };
-        auto commit = [&](float* buf) {
-#pragma unroll
-            for (int i = 0; i < NSTG; ++i) {
-                const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-                const bool ok = (svalid >> i) & 1u;          // component-wise selects: keeps stg[] in registers
-                *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
-                    make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
-            }
-        };
-        zero_acc(acc);
-        issue(__ffs(tapmask) - 1);
-        commit(sBuf[0]);
-        __syncthreads();
-        int buf = 0;
-#pragma unroll 1
-        while (tapmask) {
-            tapmask &= tapmask - 1;                            // the tap being multiplied now is already in bcur
-            const bool more = tapmask != 0;
-            const int tn = __ffs(tapmask) - 1;
-            // next stage's weights first (older in the in-order vmcnt queue), then the next activation tile
-            load_b(bnext, more ? w.dyn_conv_p + (size_t)tn * 16384 : w.dyn_dense_p, lane, wave);
-            if (more) issue(tn);
-            mma_tile<MT>(sBuf[buf], bcur, acc, lane);
-            if (more) commit(sBuf[buf ^ 1]);
-            __syncthreads();
-            bcur = bnext;
-            buf ^= 1;
-        }
-        // + bias + action planes, relu -> sX
-        load_b(bnext, w.pred_conv_p + (size_t)cell * 16384, lane, wave);
-        const int n = wave * 32 + (lane & 31);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(m, r, lane);
-                const float v = acc[m][r] + w.dyn_actbias[(sAct[row] * 9 + cell) * 128 + n];
-                sX[row * kLd + n] = fmaxf(v, 0.f);
-            }
-        __syncthreads();
     }
 
-    // Dense 128 -> 128, relu = the new hidden state of this cell (games/tictactoe.py:184 / :191)
+    // Dense 128 -> 128, relu = the hidden state of this cell (games/tictactoe.py:184)
     zero_acc(acc);
     mma_tile<MT>(sX, bcur, acc, lane);
     {
-        const float* bias = INITIAL ? w.rep_dense_b : w.dyn_dense_b;
         const int n = wave * 32 + (lane & 31);
-        const float bn = bias[n];
+        const float bn = w.rep_dense_b[n];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -316,18 +220,11 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
                 const int row = acc_row(m, r, lane);
                 const float v = fmaxf(acc[m][r] + bn, 0.f);
                 sH[row * kLd + n] = v;
-                if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;
+                if (row0 + row < B) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;
             }
     }
     __syncthreads();
-
-    if (!INITIAL && tid < ROWS * 4) {
-        // reward head partial: Flatten(1152) . w restricted to this cell (games/tictactoe.py:193-195)
-        const int row = tid >> 2, q = tid & 3;
-        const float s = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
-        if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = s;
-    }
-    // prediction Conv2D 3x3 valid over the 3x3 board = sum over cells of hidden'[cell] @ W[cell]: this cell's term
+    // prediction Conv2D 3x3 valid over the 3x3 board = sum over cells of hidden[cell] @ W[cell]: this cell's term
     zero_acc(acc);
     mma_tile<MT>(sH, bnext, acc, lane);
     {
@@ -337,15 +234,8 @@ __global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = acc_row(m, r, lane);
-                if (sRowOff[row] >= 0) ppart[((size_t)(row0 + row) * 9 + cell) * 128 + n] = acc[m][r];
+                if (row0 + row < B) ppart[((size_t)(row0 + row) * 9 + cell) * 128 + n] = acc[m][r];
             }
-    }
-    if (trace && threadIdx.x == 0) {       // diagnostic timeline (mzdbg_net_set_trace): start, end [10 ns], placement
-        long long* tr = trace + 8 * (size_t)blockIdx.x;
-        tr[0] = t_start;
-        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
-                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 }
 
@@ -405,8 +295,7 @@ __device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& a
 __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, const float* __restrict__ in_base,
                                                               const int* __restrict__ parent_block, long block_stride,
                                                               const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                              float* __restrict__ ppart, float* __restrict__ rpart,
-                                                              long long* __restrict__ trace) {
+                                                              float* __restrict__ ppart, float* __restrict__ rpart) {
     constexpr int ROWS = 32;
     __shared__ __attribute__((aligned(16))) float sTile[2][ROWS * kLd];
     __shared__ __attribute__((aligned(16))) float sX[ROWS * kLd];
@@ -414,7 +303,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
     __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
-    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
     const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -540,14 +428,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, c
             if (gather) buf ^= 1;
             if (!has_next) copy_out(sX, ppart + job * 128, 1152);
         }
-    }
-    if (trace && threadIdx.x == 0) {
-        long long* tr = trace + 8 * (size_t)blockIdx.x;
-        tr[0] = t_start;
-        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
-                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[3] = job;
     }
 }
 
@@ -1352,177 +1232,6 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     }
 }
 
-// Diagnostic twin of ttt_job_kernel with in-kernel segment stamps (tools/trace_cell.py); never used by the product path.
-__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_traced(TttDev w, int B, const float* __restrict__ in_base,
-                                                              const int* __restrict__ parent_block, long block_stride,
-                                                              const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                              float* __restrict__ ppart, float* __restrict__ rpart,
-                                                              long long* __restrict__ trace) {
-    constexpr int ROWS = 32;
-    __shared__ __attribute__((aligned(16))) float sTile[2][ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sX[ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sH[ROWS * kLd];
-    __shared__ long sRowOff[ROWS];
-    __shared__ int sAct[ROWS];
-    __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
-    const long long t_start = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    const long long c_start = trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + ROWS - 1) / ROWS;
-    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
-    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
-    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
-    const int row0 = rb * ROWS;
-    const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
-    const int n = wave * 32 + (lane & 31);
-    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_p) + n * 2 + (lane >> 5);   // + weights offset / 4
-
-    BFrag bw;
-    const int4 D0 = w.job_desc[dbase];
-    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
-    load_b(bw, w.dyn_conv_p + (size_t)D0.z * 16384, lane, wave);
-    if (tid < ROWS) {
-        const int b = row0 + tid;
-        long off = -1;
-        int a = 0;
-        if (b < B) {
-            const int pb = parent_block ? parent_block[b] : 0;
-            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-            a = action[b];
-            if (a < 0 || a > 8) a = 0;
-        }
-        sRowOff[tid] = off;
-        sAct[tid] = a;
-    }
-    __syncthreads();
-    const float* sptr[4];
-    unsigned svalid = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-        const long off = sRowOff[r];
-        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
-        if (off >= 0) svalid |= 1u << i;
-    }
-    float4 stg[4];
-    auto commit = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            const bool ok = (svalid >> i) & 1u;
-            *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
-                make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
-        }
-    };
-    // LDS tile -> global rows (stride `ld` floats), 16-B coalesced, skipped rows masked
-    auto copy_out = [&](const float* sSrc, float* dst, int ld) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            if ((svalid >> i) & 1u)
-                *reinterpret_cast<float4*>(dst + (size_t)(row0 + r) * ld + c4 * 4) =
-                    *reinterpret_cast<const float4*>(sSrc + r * kLd + c4 * 4);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
-    commit(sTile[0]);
-    __syncthreads();
-
-    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-    int buf = 0;
-    int seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0;      // diagnostic: setup / mma / epilogue+barrier / after-barrier [10 ns]
-    long long t_last = trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    const int t_pro = (int)(t_last - t_start);
-#define MZ_SEG(x)                                                            \
-    if (trace) {                                                             \
-        const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); \
-        x += (int)(now_ - t_last);                                           \
-        t_last = now_;                                                       \
-    }
-#pragma unroll 1
-    for (int d = d0; d < d1; ++d) {
-        const int4 Dc = sDesc[d];
-        const bool has_next = d + 1 < d1;
-        const int4 Dn = sDesc[has_next ? d + 1 : d];
-        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
-        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
-        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
-        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
-        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
-        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
-        const float* wn = nkind == 0 ? w.dyn_conv_p + (size_t)ntap * 16384
-                        : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
-        const bool gather = has_next && nkind == 0;
-        const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
-        if (kind == 1 || first_tap) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-        float ab[16];
-        if (kind == 0 && last_tap) {
-            // last tap of a cell: request conv bias + action-plane bias of each accumulator row now, so the loads
-            // land under the MFMAs (action planes of the one-hot encoder are constant per cell: network.py:14-40)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
-        }
-        MZ_SEG(seg0)
-        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
-        mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
-        if (kind == 2) accp = acc;
-        MZ_SEG(seg1)
-        if (kind == 0) {
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + ab[r], 0.f);
-            }
-            if (gather) commit(sTile[buf ^ 1]);
-            __syncthreads();
-            MZ_SEG(seg2)
-            if (gather) buf ^= 1;
-        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
-            const float bn = w.dyn_dense_b[n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + bn, 0.f);
-            __syncthreads();
-            MZ_SEG(seg2)
-            copy_out(sH, out_hidden + cell * 128, 1152);
-            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
-                const int row = tid >> 2, q = tid & 3;
-                const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
-                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
-            }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
-            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = accp[r];
-            }
-            if (gather) commit(sTile[buf ^ 1]);
-            __syncthreads();
-            MZ_SEG(seg2)
-            if (gather) buf ^= 1;
-            if (!has_next) copy_out(sX, ppart + job * 128, 1152);
-        }
-        MZ_SEG(seg3)
-    }
-#undef MZ_SEG
-    if (trace && threadIdx.x == 0) {
-        long long* tr = trace + 8 * (size_t)blockIdx.x;
-        tr[0] = t_start;
-        tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        tr[2] = ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) |
-                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[3] = job;
-        tr[4] = ((long long)t_pro << 32) | (unsigned)seg0;
-        tr[5] = ((long long)seg1 << 32) | (unsigned)seg2;
-        tr[6] = seg3;
-        tr[7] = (long long)__builtin_amdgcn_s_memtime() - c_start;      // shader-clock ticks (DVFS check)
-    }
-}
-
 // Prediction head of 16 games by one 256-thread workgroup: relu(sum of the NP partial products + bias)
 // (games/tictactoe.py:201) -> Dense 128 -> 128 relu (:204) -> value (tanh, :206) and the 9 policy logits (:208), and
 // the reward head's tanh over the 9 per-cell partial dots (:193-195).  Split-f16 arithmetic like the job kernel
@@ -2223,7 +1932,6 @@ struct mz_net {
     int scratch_cap = 0;
     bool hidden_split = false;        // inside a native move: the hidden workspace holds split images (mz_net_begin_move)
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
-    long long* trace = nullptr;       // diagnostic: per-workgroup timeline of the cell kernel (device, 3 x grid)
 };
 
 namespace {
@@ -2569,12 +2277,6 @@ int mz_debug_net_trace(uint32_t* out, int64_t out_bytes) {
 }
 #endif
 
-/* Diagnostic, not part of include/mzhip.h: device buffer of 3 int64 per workgroup of the next cell-kernel launches. */
-int mzdbg_net_set_trace(mz_net_t* net, long long* device_buf) {
-    if (net) net->trace = device_buf;
-    return MZ_OK;
-}
-
 int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     net->mid_event = static_cast<hipEvent_t>(hip_event);
@@ -2583,14 +2285,6 @@ int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
 
 // Rows per workgroup tile (32 or 64).  64 halves the weight traffic per game; 32 doubles the number of
 // workgroups, which wins while a 64-row grid cannot fill the 256 CUs.  MZ_TILE_ROWS overrides (experiments).
-static int cell_order() {
-    static const int v = [] {
-        const char* e = getenv("MZ_CELL_ORDER");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-
 static int tile_rows(const mz_net* net, int batch) {
     static const int forced = [] {
         const char* e = getenv("MZ_TILE_ROWS");
@@ -2618,13 +2312,9 @@ static int infer_initial(mz_net_t* net, int32_t batch, const float* observation,
         const int nhb = (batch + 15) / 16;
         if (job_f32()) {
             if (rows == 64)
-                ttt_cell_kernel<true, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
-                                                                      out_hidden, net->ppart, net->rpart, cell_order(),
-                                                                      net->trace);
+                ttt_cell_kernel<2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, out_hidden, net->ppart);
             else
-                ttt_cell_kernel<true, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, nullptr, 0, nullptr,
-                                                                      out_hidden, net->ppart, net->rpart, cell_order(),
-                                                                      net->trace);
+                ttt_cell_kernel<1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, out_hidden, net->ppart);
             if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
             ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
                                                               out_value, out_logits, out_value_raw);
@@ -2677,39 +2367,21 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
-        static const bool per_cell = getenv("MZ_CELL_KERNEL") != nullptr;      // the older per-cell grid (experiments)
-        if (!per_cell) {
-            const int nrb32 = (batch + 31) / 32;
-            if (net->trace)
-                ttt_job_kernel_traced<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(
-                    net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart, net->trace);
-            else if (job_f32())
-                ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
-                                                                            action, out_hidden, net->ppart, net->rpart,
-                                                                            nullptr);
-            else if (job_rows32())
-                ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base,
-                                                                                     parent_block, bs, action, out_hidden,
-                                                                                     net->ppart, net->rpart);
-            else
-                ttt_job_kernel_w<false><<<32 * (((batch + 63) / 64 + 7) / 8), kThreadsW, 0, st>>>(
-                    net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart);
-        } else if (rows == 64)
-            ttt_cell_kernel<false, 2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                   out_hidden, net->ppart, net->rpart, cell_order(),
-                                                                   net->trace);
+        const int nrb32 = (batch + 31) / 32;
+        if (job_f32())
+            ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
+                                                                        action, out_hidden, net->ppart, net->rpart);
+        else if (job_rows32())
+            ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
+                                                                                 bs, action, out_hidden, net->ppart,
+                                                                                 net->rpart);
         else
-            ttt_cell_kernel<false, 1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                   out_hidden, net->ppart, net->rpart, cell_order(),
-                                                                   net->trace);
+            ttt_job_kernel_w<false><<<32 * (((batch + 63) / 64 + 7) / 8), kThreadsW, 0, st>>>(
+                net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
-        if (per_cell)
-            ttt_head_kernel<false, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                               out_reward, out_value, out_logits, out_value_raw);
-        else
-            ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
-                                                               out_reward, out_value, out_logits, out_value_raw);
+        ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+                                                           out_reward, out_value, out_logits, out_value_raw);
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<false><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs,
                                                                           action, out_hidden, out_reward, out_value,
@@ -2746,7 +2418,7 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     MZ_REQUIRE(net->device == pool->device && net->stream == pool->stream, "net and pool must share device and stream");
     const int batch = pool->dev.T;
     static const bool no_fusion = getenv("MZ_NO_FUSED_STEP") != nullptr;          // experiments
-    const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9 && !net->trace && !no_fusion;
+    const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9 && !no_fusion;
     if (!fusable) {                                   // the same work as separate launches
         int s = mz_infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward,
                                    out_value, out_logits, nullptr);
@@ -2766,7 +2438,7 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     if (job_f32())
         ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
                                                                     (long)block_stride, action, out_hidden, net->ppart,
-                                                                    net->rpart, nullptr);
+                                                                    net->rpart);
     else if (job_rows32()) {
         if (net->hidden_split)
             ttt_job_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,

@@ -241,6 +241,10 @@ def test_native_move_equals_python_driven_move():
         assert torch.equal(x, y)
     # The hidden workspace of a native move belongs to the network: for TicTacToe every (game, cell) row of 128 floats
     # holds its split image, [128 h | 128 l] halfs with value = h + l / 2048 (21 bits; mz_net.hip, SPLIT_IO).
+    import os
+    if os.environ.get('MZ_JOB_F32'):                 # the f32-MFMA comparison path keeps f32 rows
+        assert torch.equal(hidden_a, search.hidden)
+        return
     img = search.hidden.view(torch.float16).reshape(-1, 2, 128).double()
     decoded = (img[:, 0] + img[:, 1] / 2048.0).reshape(hidden_a.shape)
     assert torch.allclose(decoded, hidden_a.double(), rtol=2.0 ** -20, atol=1e-9)
