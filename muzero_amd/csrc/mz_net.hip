@@ -1030,15 +1030,13 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
             {
                 const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol);
                 const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol);
+                float rdot[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
                                         fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
-                    // reward head (games/tictactoe.py:193-195): this lane's four columns, then the wave's sixteen
-                    float rdot = __builtin_fmaf(v[3], rw.w, __builtin_fmaf(v[2], rw.z, __builtin_fmaf(v[1], rw.y, v[0] * rw.x)));
-                    rdot += __shfl_xor(rdot, 16);
-                    rdot += __shfl_xor(rdot, 32);
-                    if (g == 0) sRew[wave * ROWS + 16 * m + n16] = rdot;
+                    // reward head (games/tictactoe.py:193-195): this lane's four columns
+                    rdot[m] = __builtin_fmaf(v[3], rw.w, __builtin_fmaf(v[2], rw.z, __builtin_fmaf(v[1], rw.y, v[0] * rw.x)));
                     uint2 h, l;
                     split4(v, h, l);
                     _Float16* row = sH + (16 * m + n16) * kLdW + lcol;
@@ -1047,6 +1045,15 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     if (!SPLIT_IO && ((rowmask >> (16 * m + n16)) & 1ull))                      // f32, unsplit
                         *reinterpret_cast<float4*>(ocell + (unsigned)(16 * m + n16) * 1152u + lcol) =
                             make_float4(v[0], v[1], v[2], v[3]);
+                }
+                // ... then the wave's sixteen columns: lanes n16 + 16 g, g = 0..3, hold the four parts of game n16
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned x = __float_as_uint(rdot[m]);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+                    const unsigned y = __float_as_uint(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+                    if (g == 0) sRew[wave * ROWS + 16 * m + n16] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
                 }
             }
             MZ_TRACE_NW(3);
