@@ -1467,6 +1467,14 @@ struct CartDev {
     const float* pred_value_b;  // [128], entries >= 101 zero
     const float* pred_policy_w; // [2][128]
     const float* pred_policy_b; // [2]
+    // the seven 128 x 128 operands again as split-f16 fragments (Packer::add_split16): cartpole16_kernel
+    const float* rep_dense_s;
+    const float* dyn_conv_s;
+    const float* dyn_dense_s;
+    const float* dyn_rdense_s;
+    const float* pred_dense1_s;
+    const float* pred_dense2_s;
+    const float* pred_value_s;
     float dyn_reward_b;
 };
 
@@ -1644,46 +1652,48 @@ __global__ __launch_bounds__(kThreads) void cartpole_kernel(CartDev w, int B, co
     }
 }
 
-// ------------------------------------------------------------------------------------------------ host side
-// Latency-oriented CartPole inference for small batches: 16 games per 512-thread workgroup on v_mfma_f32_16x16x4_f32.
-// The 32-row kernel above runs 64 dependent 64-cycle MFMAs per wavefront and stage (1024 games = 32 workgroups on 256
-// CUs, 25 us a call); here eight wavefronts own 16 output columns each and split K into two accumulator chains, so a
-// stage is 2 x 16 dependent 32-cycle MFMAs.  Same stages, same packed weights, same outputs.
+// CartPole on 16-game tiles (batches <= kCart16MaxBatch).  The 32-row kernel above is a latency chain of six stages per
+// wavefront (1024 games = 32 workgroups on 256 CUs, 25 us a call); here a workgroup is 16 games x 512 threads, eight
+// wavefronts own 16 output columns each, and the arithmetic is the split-f16 scheme of the TicTacToe kernels
+// (v = h + l/2048, three exact f16 products per f32 product, f32 accumulation) on v_mfma_f32_16x16x32_f16: a stage is
+// 4 k-steps x 3 MFMAs of 16 cycles, where the f32 version ran 2 x 16 dependent 32-cycle MFMAs.  Weights as the row
+// operand: a lane holds four consecutive columns of game lane % 16.  Same stages and outputs as cartpole_kernel.
 struct BFrag16 {
-    float2 v[16];
+    float4 v[8];                   // [k-step][h | l] of this wave's 16 columns
 };
-// W packed [16][128][8]: lane (n = 16*wave + lane%16, q = lane/16) takes k = 8*kb + 2*q, +1
-__device__ __forceinline__ void load_b16(BFrag16& b, const float* __restrict__ Wp, int lane, int wave) {
-    const float2* wp = reinterpret_cast<const float2*>(Wp) + (size_t)(wave * 16 + (lane & 15)) * 4 + (lane >> 4);
+__device__ __forceinline__ void load_b16(BFrag16& b, const float* __restrict__ Ws, int lane, int wave) {
+    const float4* wp = reinterpret_cast<const float4*>(Ws) + wave * 64 + lane;       // Packer::add_split16
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) b.v[kb] = wp[kb * 512];
+    for (int j = 0; j < 8; ++j) b.v[j] = wp[j * 512];
 }
-// sA[16][128] (LDS, stride kLd) * W[128][this wave's 16 columns]; C/D layout: [i] = row 4*(lane/16) + i, column lane%16
-__device__ __forceinline__ f32x4 mma16(const float* sA, const BFrag16& b, int lane) {
-    const float* ap = sA + (lane & 15) * kLd + 2 * (lane >> 4);
-    float2 a[16];
+// sA[16][128 h | 128 l] (LDS, stride kLdW halfs) * W[128][this wave's 16 columns]; returns [i] = column 4*(lane/16) + i of
+// the wave's 16, game lane % 16
+__device__ __forceinline__ f32x4 mma16(const _Float16* sA, const BFrag16& b, int lane) {
+    const _Float16* ap = sA + (lane & 15) * kLdW + 8 * (lane >> 4);
+    float4 a[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) a[kb] = *reinterpret_cast<const float2*>(ap + kb * 8);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // even / odd kb: two chains, added at the end
-#pragma unroll
-    for (int kb = 0; kb < 16; kb += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].x, b.v[kb].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1].x, b.v[kb + 1].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].y, b.v[kb].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1].y, b.v[kb + 1].y, acc1, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) {
+        a[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
+        a[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
     }
-    return acc0 + acc1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx0 = {0.f, 0.f, 0.f, 0.f}, acx1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, a[s][0]), al = __builtin_bit_cast(f16x8, a[s][1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * s]), bl = __builtin_bit_cast(f16x8, b.v[2 * s + 1]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc, 0, 0, 0);
+        acx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx0, 0, 0, 0);
+        acx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx1, 0, 0, 0);
+    }
+    return acc + (acx0 + acx1) * kUnsplit;
 }
-// dot of a 128-float LDS row with 128 weights by the 16 threads of a row (q = 0..15 takes 8 floats each, its 8 weights
-// already in registers); all 16 get the sum
-__device__ __forceinline__ float dot8x16(const float* h, const float4& b0, const float4& b1, int q) {
-    const float4 a0 = *reinterpret_cast<const float4*>(h + 8 * q), a1 = *reinterpret_cast<const float4*>(h + 8 * q + 4);
-    float s = a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
-    s += __shfl_xor(s, 1, 16);
-    s += __shfl_xor(s, 2, 16);
-    s += __shfl_xor(s, 4, 16);
-    s += __shfl_xor(s, 8, 16);
-    return s;
+// sum over the four lanes n16 + 16 g of a game (the wave's sixteen columns); every lane gets it
+__device__ __forceinline__ float sum_over_g(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned y = __float_as_uint(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
 constexpr int kThreads16 = 512;
@@ -1697,29 +1707,29 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
                                                                 float* __restrict__ out_value, float* __restrict__ out_logits,
                                                                 float* __restrict__ out_value_raw) {
     constexpr int ROWS = 16;
-    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
+    __shared__ __attribute__((aligned(16))) _Float16 sBuf[2][ROWS * kLdW];      // split activation tiles
+    __shared__ __attribute__((aligned(16))) float sV[ROWS * kLd];                // the 101 value logits, f32
+    __shared__ float sPart[3][8][ROWS];              // reward / policy 0 / policy 1 partial dots of the eight waves
     __shared__ long sRowOff[ROWS];
     __shared__ float sAct[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n16 = lane & 15, q4 = lane >> 4;
-    const int n = wave * 16 + n16;                       // this lane's output column
+    const int n16 = lane & 15, g = lane >> 4;
+    const int lcol = wave * 16 + 4 * g;                  // this lane's four output columns, of game n16
     const int row0 = blockIdx.x * ROWS;
-    float* sX = sBuf[0];
-    float* sH = sBuf[1];
+    _Float16* sX = sBuf[0];
+    _Float16* sH = sBuf[1];
     // Every bias and head weight this thread will need, requested first: vmcnt is in-order, so a load issued in an
     // epilogue would wait for the weight fragments of the stage after next that are requested ahead of it.
-    const int hq = tid & 15;                             // this thread's eighth of a head's 128 weights
-    const float bias_hidden = (INITIAL ? w.rep_dense_b : w.dyn_dense_b)[n];
-    const float bias_conv = INITIAL ? 0.f : w.dyn_conv_b[n], plane = INITIAL ? 0.f : w.dyn_plane[n];
-    const float bias_rdense = INITIAL ? 0.f : w.dyn_rdense_b[n];
-    const float bias_p1 = w.pred_dense1_b[n], bias_p2 = w.pred_dense2_b[n], bias_value = w.pred_value_b[n];
-    const float4* rwp = reinterpret_cast<const float4*>(w.dyn_reward_w + 8 * hq);
-    const float4* pwp = reinterpret_cast<const float4*>(w.pred_policy_w + 8 * hq);
-    const float4 rw0 = INITIAL ? make_float4(0.f, 0.f, 0.f, 0.f) : rwp[0], rw1 = INITIAL ? rw0 : rwp[1];
-    const float4 pw00 = pwp[0], pw01 = pwp[1], pw10 = pwp[32], pw11 = pwp[33];
+    auto f4 = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr + lcol); };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bias_hidden = f4(INITIAL ? w.rep_dense_b : w.dyn_dense_b);
+    const float4 bias_conv = INITIAL ? zero4 : f4(w.dyn_conv_b), plane = INITIAL ? zero4 : f4(w.dyn_plane);
+    const float4 bias_rdense = INITIAL ? zero4 : f4(w.dyn_rdense_b), rw = INITIAL ? zero4 : f4(w.dyn_reward_w);
+    const float4 bias_p1 = f4(w.pred_dense1_b), bias_p2 = f4(w.pred_dense2_b), bias_value = f4(w.pred_value_b);
+    const float4 pw0 = f4(w.pred_policy_w), pw1 = f4(w.pred_policy_w + 128);
     const float policy_b0 = w.pred_policy_b[0], policy_b1 = w.pred_policy_b[1];
     BFrag16 b0, b1;
-    load_b16(b0, INITIAL ? w.rep_dense_p : w.dyn_conv_p, lane, wave);
+    load_b16(b0, INITIAL ? w.rep_dense_s : w.dyn_conv_s, lane, wave);
     if (tid < ROWS) {
         const int b = row0 + tid;
         long off = -1;
@@ -1737,15 +1747,25 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
         sAct[tid] = a;
     }
     __syncthreads();
-    // stores relu(acc + bias (+ extra)) of this wave's 16 columns into an LDS tile
-    auto store = [&](const f32x4& acc, float bias, float* sOut, bool relu) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = acc[i] + bias;
-            sOut[(4 * q4 + i) * kLd + n] = relu ? fmaxf(v, 0.f) : v;
-        }
+    const bool lrow_ok = sRowOff[n16] >= 0;
+    // relu(acc + bias) of this lane's four columns (v), stored as a split row piece
+    auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
+        v[0] = fmaxf(acc[0] + bias.x, 0.f);
+        v[1] = fmaxf(acc[1] + bias.y, 0.f);
+        v[2] = fmaxf(acc[2] + bias.z, 0.f);
+        v[3] = fmaxf(acc[3] + bias.w, 0.f);
+    };
+    auto store4 = [&](const float (&v)[4], _Float16* sOut) {
+        uint2 h, l;
+        split4(v, h, l);
+        *reinterpret_cast<uint2*>(sOut + n16 * kLdW + lcol) = h;
+        *reinterpret_cast<uint2*>(sOut + n16 * kLdW + 128 + lcol) = l;
+    };
+    auto dot4 = [&](const float (&v)[4], const float4& wv) {
+        return __builtin_fmaf(v[3], wv.w, __builtin_fmaf(v[2], wv.z, __builtin_fmaf(v[1], wv.y, v[0] * wv.x)));
     };
     f32x4 acc;
+    float v[4];
     if (INITIAL) {
         // scalar_to_support two-hot (utils.py:138-143, network.py:107-116) -> Conv1D k=4 valid 101 -> 128 relu
         // (games/cartpole.py:98): only <= 8 of the 404 inputs are non-zero, gathered on the VALU.
@@ -1767,72 +1787,87 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
                     if (il >= 0 && il <= 100) s += (1.f - pf) * w.rep_conv[(pos * 101 + il) * 128 + nn];
                 }
             }
-            sX[r * kLd + nn] = fmaxf(s, 0.f);
+            _Float16 h, l;
+            split_f16(fmaxf(s, 0.f), h, l);
+            sX[r * kLdW + nn] = h;
+            sX[r * kLdW + 128 + nn] = l;
         }
-        load_b16(b1, w.pred_dense1_p, lane, wave);
+        load_b16(b1, w.pred_dense1_s, lane, wave);
         __syncthreads();
         acc = mma16(sX, b0, lane);                                            // Dense relu = hidden (:101)
     } else {
-        {   // gather leaf.parent.hidden_state rows (agent.py:204) into LDS: 16 rows x 32 float4
+        {   // gather leaf.parent.hidden_state rows (agent.py:204) into LDS: 16 rows x 32 pieces of four floats
             const int r = tid >> 5, c4 = tid & 31;
             const long off = sRowOff[r];
-            const float4 v = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(sH + r * kLd + c4 * 4) = v;
+            const float4 x = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : zero4;
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+            uint2 h, l;
+            split4(xv, h, l);
+            *reinterpret_cast<uint2*>(sH + r * kLdW + c4 * 4) = h;
+            *reinterpret_cast<uint2*>(sH + r * kLdW + 128 + c4 * 4) = l;
         }
-        load_b16(b1, w.dyn_dense_p, lane, wave);
+        load_b16(b1, w.dyn_dense_s, lane, wave);
         __syncthreads();
         // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
         acc = mma16(sH, b0, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * q4 + i;
-            sX[row * kLd + n] = fmaxf(acc[i] + bias_conv + sAct[row] * plane, 0.f);
+        {
+            const float a = sAct[n16];
+            const float4 bc = make_float4(bias_conv.x + a * plane.x, bias_conv.y + a * plane.y, bias_conv.z + a * plane.z,
+                                          bias_conv.w + a * plane.w);
+            act4(acc, bc, v);
+            store4(v, sX);
         }
-        load_b16(b0, w.dyn_rdense_p, lane, wave);
+        load_b16(b0, w.dyn_rdense_s, lane, wave);
         __syncthreads();
         acc = mma16(sX, b1, lane);                                            // Dense relu = hidden' (:108)
-        load_b16(b1, w.pred_dense1_p, lane, wave);
+        load_b16(b1, w.pred_dense1_s, lane, wave);
     }
-    {   // hidden state out (both modes); sH's previous contents (the gathered input) are no longer read
+    // hidden state out (both modes); sH's previous contents (the gathered input) are no longer read
+    act4(acc, bias_hidden, v);
+    store4(v, sH);
+    if (lrow_ok) *reinterpret_cast<float4*>(out_hidden + (size_t)(row0 + n16) * 128 + lcol) = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
+    if (!INITIAL) {
+        // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114); the dot from the accumulators
+        acc = mma16(sH, b0, lane);
+        act4(acc, bias_rdense, v);
+        const float part = sum_over_g(dot4(v, rw));
+        if (g == 0) sPart[0][wave][n16] = part;
+    }
+    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124); b1 = pred_dense1 in both modes
+    load_b16(b0, w.pred_dense2_s, lane, wave);
+    acc = mma16(sH, b1, lane);
+    act4(acc, bias_p1, v);
+    store4(v, sX);
+    load_b16(b1, w.pred_value_s, lane, wave);
+    __syncthreads();                                     // sX complete, sH no longer read, sPart[0] complete
+    if (!INITIAL && tid < ROWS && sRowOff[tid] >= 0) {
+        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * q4 + i;
-            const float v = fmaxf(acc[i] + bias_hidden, 0.f);
-            sH[row * kLd + n] = v;
-            if (sRowOff[row] >= 0) out_hidden[(size_t)(row0 + row) * 128 + n] = v;
+        for (int k = 0; k < 8; ++k) s += sPart[0][k][tid];
+        out_reward[row0 + tid] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+    }
+    acc = mma16(sX, b0, lane);
+    act4(acc, bias_p2, v);
+    store4(v, sH);
+    {   // policy logits: Dense 2 (:127), from the accumulators
+        const float p0 = sum_over_g(dot4(v, pw0)), p1 = sum_over_g(dot4(v, pw1));
+        if (g == 0) {
+            sPart[1][wave][n16] = p0;
+            sPart[2][wave][n16] = p1;
         }
     }
+    __syncthreads();
+    // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
+    acc = mma16(sH, b1, lane);
+    *reinterpret_cast<float4*>(sV + n16 * kLd + lcol) =
+        make_float4(acc[0] + bias_value.x, acc[1] + bias_value.y, acc[2] + bias_value.z, acc[3] + bias_value.w);
     __syncthreads();
     const int row = (tid >> 4) & 15, q = tid & 15, b = row0 + row;        // 16 threads per row (threads 0..255)
     const bool rowthread = tid < ROWS * 16;
     const bool live = rowthread && sRowOff[row] >= 0;
-    if (!INITIAL) {
-        // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114)
-        acc = mma16(sH, b0, lane);
-        store(acc, bias_rdense, sX, true);
-        __syncthreads();
-        if (rowthread) {
-            const float s = dot8x16(sX + row * kLd, rw0, rw1, q);
-            if (q == 0 && live) out_reward[b] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
-        }
-        __syncthreads();
-    }
-    // prediction: Dense relu, Dense relu (games/cartpole.py:121-124); b1 = pred_dense1 in both modes
-    load_b16(b0, w.pred_dense2_p, lane, wave);
-    acc = mma16(sH, b1, lane);
-    store(acc, bias_p1, sX, true);
-    load_b16(b1, w.pred_value_p, lane, wave);
-    __syncthreads();
-    acc = mma16(sX, b0, lane);
-    __syncthreads();
-    store(acc, bias_p2, sH, true);
-    __syncthreads();
-    // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
-    acc = mma16(sH, b1, lane);
-    store(acc, bias_value, sX, false);
-    __syncthreads();
     if (rowthread) {
-        float* z = sX + row * kLd;
+        float* z = sV + row * kLd;
         float mx = -INFINITY;
         for (int j = q; j < 101; j += 16) mx = fmaxf(mx, z[j]);
 #pragma unroll
@@ -1858,11 +1893,11 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
             const float t = (sqrtf(2.f) - 1.f) * y + 1.f;
             out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
         }
-        // policy logits: Dense 2 (:127)
-        const float s0 = dot8x16(sH + row * kLd, pw00, pw01, q), s1 = dot8x16(sH + row * kLd, pw10, pw11, q);
-        if (q == 0 && live) {
-            out_logits[(size_t)b * 2] = s0 + policy_b0;
-            out_logits[(size_t)b * 2 + 1] = s1 + policy_b1;
+        if (q < 2 && live) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += sPart[1 + q][k][row];
+            out_logits[(size_t)b * 2 + q] = s + (q == 0 ? policy_b0 : policy_b1);
         }
     }
 }
@@ -2186,6 +2221,13 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             for (int o = 0; o < 2; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 2 + o];
         off.push_back(pk.add(polT));                                   // 18
         off.push_back(pk.add(pred_policy_b, 2));                       // 19
+        off.push_back(pk.add_split16(rep_dense, 128, 128));            // 20
+        off.push_back(pk.add_split16(dyn_conv, 128, 128));             // 21
+        off.push_back(pk.add_split16(dyn_dense, 128, 128));            // 22
+        off.push_back(pk.add_split16(dyn_rdense, 128, 128));           // 23
+        off.push_back(pk.add_split16(pred_dense1, 128, 128));          // 24
+        off.push_back(pk.add_split16(pred_dense2, 128, 128));          // 25
+        off.push_back(pk.add_split16(pred_value, 101, 101));           // 26
         net->cart.dyn_reward_b = dyn_reward_b[0];
     }
     hipError_t e = hipGetDevice(&net->device);
@@ -2247,6 +2289,13 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         c.pred_value_b = d + off[17];
         c.pred_policy_w = d + off[18];
         c.pred_policy_b = d + off[19];
+        c.rep_dense_s = d + off[20];
+        c.dyn_conv_s = d + off[21];
+        c.dyn_dense_s = d + off[22];
+        c.dyn_rdense_s = d + off[23];
+        c.pred_dense1_s = d + off[24];
+        c.pred_dense2_s = d + off[25];
+        c.pred_value_s = d + off[26];
     }
     *out_net = net;
     return MZ_OK;
