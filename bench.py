@@ -397,14 +397,17 @@ def main():
     mean_d = sum_d / sims_rank
     tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
+    # the TicTacToe kernels and CartPole's 16-game kernel (batches <= 8192) compute in split-f16 arithmetic
+    split_f16 = with_net and ((wl['net'] == 'tictactoe' and not os.environ.get('MZ_JOB_F32')) or
+                              (wl['net'] == 'cartpole' and wl['T'] <= 8192))
     if with_net:
         k1, rest = move.hooks.durations()
         flops_launch = move.trees_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
         traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
                                 else (None, None))
-        if wl['net'] == 'tictactoe' and not os.environ.get('MZ_JOB_F32'):
-            # The job kernel multiplies on f16 MFMA with every f32 operand split in two halfs: three f16 MFMA products
+        if split_f16:
+            # The kernel multiplies on f16 MFMA with every f32 operand split in two halfs: three f16 MFMA products
             # per algorithmic product, held to the f32 tolerance.  Priced against the f16 peak the instructions run at;
             # the f32-equivalent figures say what the same algorithmic work would need of the f32 MFMA peak.
             peak, mfma_dtype, executed = F16_MFMA_PEAK_TFLOPS, 'f16 (split f32: h + l/2048), f32 accumulate', 3 * achieved
@@ -438,7 +441,7 @@ def main():
         out = {
             'metric': 'mcts_simulations_per_sec', 'value': total_sims / elapsed, 'unit': 'simulations/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32 via split-f16 MFMA' if wl['net'] == 'tictactoe' and not os.environ.get('MZ_JOB_F32') else 'f32') if with_net else 'f64',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32 via split-f16 MFMA' if split_f16 else 'f32') if with_net else 'f64',
             'data': 'synthetic',
             'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'lanes_per_gpu': args.lanes,
                        'actions': wl['A'],
