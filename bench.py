@@ -178,8 +178,8 @@ class HipEvents:
 
 class MoveEvents:
     """HIP events for a sample of a move's simulations, recorded by mz_search_move on the launch stream: [0] before the
-    inference, [1] after its dominant kernel (TicTacToe: the job kernel; CartPole: the whole inference), [2] after the
-    tree step (TicTacToe: head + tree step are one launch).  A record costs ~13 us of stream time, so only every
+    inference, [1] after its dominant kernel (TicTacToe: the job kernel; CartPole: the whole simulation, network and
+    tree step being one launch for batches <= 8192), [2] after the tree step (TicTacToe: head + tree step are one launch).  A record costs ~13 us of stream time, so only every
     `stride`-th simulation of a sampled step is timed."""
 
     def __init__(self, num_simulations, stride):
@@ -243,7 +243,8 @@ class NetworkMove:
         else:
             span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
             self.obs = ((torch.rand(T, 4, generator=g, device=device) * 2 - 1) * span).contiguous()
-            self.dominant = 'cartpole16_kernel<false>' if T <= 8192 else 'cartpole_kernel<false'
+            # batches <= 8192: network and tree step of 16 games fused in one kernel (cartpole16_step_kernel)
+            self.dominant = 'cartpole16_step_kernel' if T <= 8192 else 'cartpole_kernel<false'
             self.flops_per_eval = 223232
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
@@ -419,7 +420,8 @@ def main():
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
                     'executed_mfma_tflops': executed, 'executed_frac': executed / peak,
                     'f32_equivalent': {'peak': F32_MFMA_PEAK_TFLOPS, 'frac': achieved / F32_MFMA_PEAK_TFLOPS}}
-        rest_name = 'head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else 'tree_step_kernel_us'
+        rest_name = ('head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else
+                     'after_fused_kernel_us' if move.dominant == 'cartpole16_step_kernel' else 'tree_step_kernel_us')
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         network = f"{wl['net']} network, random-init weights, f32 results (1e-5 of the fp64 oracle)"

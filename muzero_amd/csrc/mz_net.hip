@@ -1699,14 +1699,20 @@ __device__ __forceinline__ float sum_over_g(float x) {
 constexpr int kThreads16 = 512;
 constexpr int kCart16MaxBatch = 8192;      // up to two 16-game workgroups per CU; larger batches take the 32/64-row tiles
 
-template <bool INITIAL>
-__global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B, const float* __restrict__ in_base,
-                                                                const int* __restrict__ parent_block, long block_stride,
-                                                                const int* __restrict__ action,
-                                                                float* __restrict__ out_hidden, float* __restrict__ out_reward,
-                                                                float* __restrict__ out_value, float* __restrict__ out_logits,
-                                                                float* __restrict__ out_value_raw) {
+// FUSE: 0 = the network alone; 1 = + expand and backprop of this simulation for the 16 games (mz_expand_backprop_logits),
+// 2 = + select of the next one (mz_step_logits), by wave 0 with two lanes per game -- exactly step_kernel<2, 1, true>'s
+// code (mz_tree_dev.h), fed through LDS: one launch per simulation.  parent_block / action are then read at the start and
+// rewritten at the end, each workgroup its own 16 games.
+template <bool INITIAL, int FUSE>
+__device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const float* __restrict__ in_base,
+                                                int* parent_block, long block_stride, int* action,
+                                                float* __restrict__ out_hidden, float* __restrict__ out_reward,
+                                                float* __restrict__ out_value, float* __restrict__ out_logits,
+                                                float* __restrict__ out_value_raw, const PoolDev& p, int nb) {
     constexpr int ROWS = 16;
+    constexpr int G = 2, PB = TreeLds<G>::kPB;
+    __shared__ __attribute__((aligned(16))) float sTreeRows[FUSE ? ROWS * TreeLds<G>::kRow : 4];
+    __shared__ float sOut[ROWS][4];                  // reward, value, the two logits: the tree step's inputs
     __shared__ __attribute__((aligned(16))) _Float16 sBuf[2][ROWS * kLdW];      // split activation tiles
     __shared__ __attribute__((aligned(16))) float sV[ROWS * kLd];                // the 101 value logits, f32
     __shared__ float sPart[3][8][ROWS];              // reward / policy 0 / policy 1 partial dots of the eight waves
@@ -1718,6 +1724,14 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
     const int row0 = blockIdx.x * ROWS;
     _Float16* sX = sBuf[0];
     _Float16* sH = sBuf[1];
+    // the tree step's lanes: wave 0, lanes 0..31 = 16 games x 2; the others come along inactive, outside every tree
+    const int tree = (FUSE && tid < ROWS * G) ? row0 + tid / G : p.T, gl = tid % G;
+    bool tree_active = false;
+    BackupPrefetchT<PB> pf;
+    if (FUSE && wave == 0) {
+        tree_active = tree < p.T && p.n_root[tree] > 0;
+        pf = backprop_prefetch<G, PB>(p, tree, tree_active, gl);              // lands while the network computes
+    }
     // Every bias and head weight this thread will need, requested first: vmcnt is in-order, so a load issued in an
     // epilogue would wait for the weight fragments of the stage after next that are requested ahead of it.
     auto f4 = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr + lcol); };
@@ -1845,7 +1859,9 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += sPart[0][k][tid];
-        out_reward[row0 + tid] = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        const float r = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+        out_reward[row0 + tid] = r;
+        sOut[tid][0] = r;
     }
     acc = mma16(sX, b0, lane);
     act4(acc, bias_p2, v);
@@ -1891,15 +1907,57 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B
         if (q == 0 && live) {
             y = y / 100.f;
             const float t = (sqrtf(2.f) - 1.f) * y + 1.f;
-            out_value[b] = 0.f + (100.f - 0.f) * (t * t - 1.f);        // config.py:38-40 with bounds (0,100)
+            const float val = 0.f + (100.f - 0.f) * (t * t - 1.f);     // config.py:38-40 with bounds (0,100)
+            out_value[b] = val;
+            sOut[row][1] = val;
         }
         if (q < 2 && live) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += sPart[1 + q][k][row];
-            out_logits[(size_t)b * 2 + q] = s + (q == 0 ? policy_b0 : policy_b1);
+            const float logit = s + (q == 0 ? policy_b0 : policy_b1);
+            out_logits[(size_t)b * 2 + q] = logit;
+            sOut[row][2 + q] = logit;
         }
     }
+    if (FUSE) {
+        __syncthreads();
+        if (wave == 0) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
+            const float* mine = sOut[tid < ROWS * G ? tid / G : 0];
+            float* lds_row = sTreeRows + (tid < ROWS * G ? tid / G : 0) * TreeLds<G>::kRow;
+            backprop_tree<G, true, PB>(p, tree, tree_active, gl, nb, mine + 2, mine[0], mine[1], pf, lds_row);
+            if (FUSE == 2) {
+                // a tree's two lanes lie inside this wavefront, whose vector memory operations are performed in program
+                // order: compiler ordering is enough (step_kernel, mz_tree.hip)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                select_tree<G>(p, tree, tree_active, gl, parent_block, action);
+            }
+        }
+    }
+}
+
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreads16) void cartpole16_kernel(CartDev w, int B, const float* __restrict__ in_base,
+                                                                const int* __restrict__ parent_block, long block_stride,
+                                                                const int* __restrict__ action,
+                                                                float* __restrict__ out_hidden, float* __restrict__ out_reward,
+                                                                float* __restrict__ out_value, float* __restrict__ out_logits,
+                                                                float* __restrict__ out_value_raw) {
+    cartpole16_body<INITIAL, 0>(w, B, in_base, const_cast<int*>(parent_block), block_stride, const_cast<int*>(action),
+                                out_hidden, out_reward, out_value, out_logits, out_value_raw, PoolDev{}, 0);
+}
+
+template <bool SELECT>
+__global__ __launch_bounds__(kThreads16) void cartpole16_step_kernel(CartDev w, PoolDev p, int nb,
+                                                                     const float* __restrict__ in_base, int* parent_block,
+                                                                     long block_stride, int* action,
+                                                                     float* __restrict__ out_hidden,
+                                                                     float* __restrict__ out_reward,
+                                                                     float* __restrict__ out_value,
+                                                                     float* __restrict__ out_logits) {
+    cartpole16_body<false, SELECT ? 2 : 1>(w, p.T, in_base, parent_block, block_stride, action, out_hidden, out_reward,
+                                           out_value, out_logits, nullptr, p, nb);
 }
 
 struct Packer {
@@ -2475,6 +2533,28 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     const int batch = pool->dev.T;
     static const bool no_fusion = getenv("MZ_NO_FUSED_STEP") != nullptr;          // experiments
     const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9 && !no_fusion;
+    const bool fusable_cart = net->kind == MZ_NET_CARTPOLE && pool->G == 2 && pool->dev.A == 2 &&
+                              batch <= kCart16MaxBatch && !no_fusion;
+    if (fusable_cart) {                               // CartPole: network and tree step of 16 games in one workgroup
+        int nb = 0;
+        int s = mz_pool_begin_backprop(pool, with_select != 0, &nb);
+        if (s != MZ_OK) return s;
+        MZ_HIP(hipSetDevice(net->device));
+        const int grid = (batch + 15) / 16;
+        if (with_select)
+            cartpole16_step_kernel<true><<<grid, kThreads16, 0, net->stream>>>(net->cart, pool->dev, nb, hidden_base,
+                                                                              parent_block, (long)block_stride, action,
+                                                                              out_hidden, out_reward, out_value, out_logits);
+        else
+            cartpole16_step_kernel<false><<<grid, kThreads16, 0, net->stream>>>(net->cart, pool->dev, nb, hidden_base,
+                                                                               parent_block, (long)block_stride, action,
+                                                                               out_hidden, out_reward, out_value, out_logits);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
+        s = launch_status("recurrent inference + tree step");
+        if (s != MZ_OK) return s;
+        mz_pool_commit_backprop(pool, with_select != 0);
+        return MZ_OK;
+    }
     if (!fusable) {                                   // the same work as separate launches
         int s = mz_infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward,
                                    out_value, out_logits, nullptr);
