@@ -192,27 +192,35 @@ __global__ void root_noise_kernel(PoolDev p, const double* noise, double frac) {
     p.root_prior[i] = p.root_prior[i] * (1 - frac) + noise[i] * frac;     // agent.py:175 (fp64, uncontracted)
 }
 
-__global__ void root_stats_kernel(PoolDev p, int* visits, double* root_value, double* minmax, float* policy) {
-    const int tree = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per tree: the rows of visits / policy are cleared and the root's children scattered into them by all
+// 64 lanes (one lane per tree took 236 us at A = 362).
+__global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
+                                                        float* policy) {
+    const int tree = blockIdx.x, lane = threadIdx.x;
     if (tree >= p.T) return;
     const int A = p.A, n = p.n_root[tree];
     const int rc = p.root_count[tree];
-    if (visits)
-        for (int a = 0; a < A; ++a) visits[(size_t)tree * A + a] = 0;
-    if (policy)
-        for (int a = 0; a < A; ++a) policy[(size_t)tree * A + a] = 0.f;
+    for (int a = lane; a < A; a += 64) {
+        if (visits) visits[(size_t)tree * A + a] = 0;
+        if (policy) policy[(size_t)tree * A + a] = 0.f;
+    }
+    // the zeros have reached memory before any lane overwrites one of them with a child's count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     const Slot* slots = f_slots(p, rec(p, tree, 0));
-    for (int k = 0; k < n; ++k) {
+    for (int k = lane; k < n; k += 64) {
         const int a = slots[k].act;
         const int c = slots[k].count;
         if (visits) visits[(size_t)tree * A + a] = c;
         if (policy) policy[(size_t)tree * A + a] = (float)((double)c / (double)rc);    // agent.py:230
     }
-    if (root_value)
-        root_value[tree] = rc > 0 ? p.root_vsum[tree] / (double)rc : std::numeric_limits<double>::quiet_NaN();
-    if (minmax) {
-        minmax[2 * tree] = p.mm_min[tree];
-        minmax[2 * tree + 1] = p.mm_max[tree];
+    if (lane == 0) {
+        if (root_value)
+            root_value[tree] = rc > 0 ? p.root_vsum[tree] / (double)rc : std::numeric_limits<double>::quiet_NaN();
+        if (minmax) {
+            minmax[2 * tree] = p.mm_min[tree];
+            minmax[2 * tree + 1] = p.mm_max[tree];
+        }
     }
 }
 
@@ -645,8 +653,8 @@ int mz_root_stats(mz_pool_t* pool, int32_t* visits, double* root_value, double* 
     MZ_REQUIRE(pool != nullptr, "pool is NULL");
     if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "root_stats before expand_roots");
     MZ_HIP(hipSetDevice(pool->device));
-    hipLaunchKernelGGL(root_stats_kernel, dim3((pool->dev.T + 63) / 64), dim3(64), 0, pool->stream, pool->dev, visits,
-                       root_value, minmax, policy);
+    hipLaunchKernelGGL(root_stats_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, visits, root_value,
+                       minmax, policy);
     return check_launch("root_stats_kernel");
 }
 
