@@ -224,29 +224,33 @@ __global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, 
     }
 }
 
-// softmax_sample (agent.py:162-168) with CPython's random.choices arithmetic; one lane per tree.
-__global__ void select_action_kernel(PoolDev p, const double* u, const double* temperature, int* out_action) {
-    const int tree = blockIdx.x * blockDim.x + threadIdx.x;
+// softmax_sample (agent.py:162-168) with CPython's random.choices arithmetic.  One wavefront per tree: the lanes read the
+// root's children and raise their counts to 1/t side by side (element-wise, so the values are those of a sequential
+// pass); the cumulative sums, whose order is part of the result, are lane 0's.
+__global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const double* u, const double* temperature,
+                                                           int* out_action) {
+    __shared__ double s_w[kMaxActions];
+    __shared__ int s_act[kMaxActions];
+    const int tree = blockIdx.x, lane = threadIdx.x;
     if (tree >= p.T) return;
     const int n = p.n_root[tree];
     if (n <= 0) {
-        out_action[tree] = -1;
+        if (lane == 0) out_action[tree] = -1;
         return;
     }
     const Slot* slots = f_slots(p, rec(p, tree, 0));
-    auto cnt = [&](int k) { return slots[k].count; };
-    auto act = [&](int k) { return slots[k].act; };
     const double t = temperature[tree];
     if (t == 0.0) {                               // max((count, action)): ties to the largest action
-        int bc = cnt(0), ba = act(0);
-        for (int k = 1; k < n; ++k) {
-            const int c = cnt(k), a = act(k);
-            if (c > bc || (c == bc && a > ba)) {
-                bc = c;
-                ba = a;
-            }
+        long long best = -1;
+        for (int k = lane; k < n; k += 64) {
+            const long long key = ((long long)slots[k].count << 32) | (unsigned)slots[k].act;
+            best = key > best ? key : best;
         }
-        out_action[tree] = ba;
+        for (int o = 32; o >= 1; o >>= 1) {
+            const long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) out_action[tree] = (int)(best & 0xffffffffll);
         return;
     }
     const double inv_t = 1 / t;
@@ -259,18 +263,24 @@ __global__ void select_action_kernel(PoolDev p, const double* u, const double* t
         }
         return pow((double)c, inv_t);
     };
+    for (int k = lane; k < n; k += 64) {
+        s_w[k] = weight(slots[k].count);
+        s_act[k] = slots[k].act;
+    }
+    __syncthreads();
+    if (lane != 0) return;
     double total = 0.0;                           // itertools.accumulate: sequential fp64 sums
-    for (int k = 0; k < n; ++k) total = (k == 0) ? weight(cnt(0)) : total + weight(cnt(k));
+    for (int k = 0; k < n; ++k) total = (k == 0) ? s_w[0] : total + s_w[k];
     const double x = u[tree] * (total + 0.0);
     // bisect_right(cum, x, 0, n-1) == number of cum[i] <= x for i < n-1 (cum is non-decreasing)
     double cum = 0.0;
     int idx = 0;
     for (int k = 0; k < n - 1; ++k) {
-        cum = (k == 0) ? weight(cnt(0)) : cum + weight(cnt(k));
+        cum = (k == 0) ? s_w[0] : cum + s_w[k];
         if (!(x < cum)) idx = k + 1;
         else break;
     }
-    out_action[tree] = act(idx);
+    out_action[tree] = s_act[idx];
 }
 
 __global__ void sum_counters_kernel(PoolDev p, long long* out2) {
@@ -663,8 +673,8 @@ int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature
     MZ_REQUIRE(u && temperature && out_action, "u, temperature and out_action must be non-NULL");
     if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "select_action before expand_roots");
     MZ_HIP(hipSetDevice(pool->device));
-    hipLaunchKernelGGL(select_action_kernel, dim3((pool->dev.T + 63) / 64), dim3(64), 0, pool->stream, pool->dev, u,
-                       temperature, out_action);
+    hipLaunchKernelGGL(select_action_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, u, temperature,
+                       out_action);
     return check_launch("select_action_kernel");
 }
 
