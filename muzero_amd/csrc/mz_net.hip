@@ -2464,9 +2464,34 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
     return infer_initial(net, batch, observation, out_hidden, out_value, out_logits, out_value_raw, false);
 }
 
-int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
-                       int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
-                       float* out_value, float* out_logits, float* out_value_raw) {
+// The split-f16 TicTacToe job kernel of this build (64-row tiles, or 32-row ones under MZ_JOB_ROWS32), reading and writing
+// f32 hidden rows or, inside a native move, their split images.
+static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, const int* parent_block, long bs,
+                              const int* action, float* out_hidden, bool split_hidden) {
+    hipStream_t st = net->stream;
+    if (job_rows32()) {
+        const int grid = 32 * (((batch + 31) / 32 + 7) / 8);
+        if (split_hidden)
+            ttt_job_kernel_h<true><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                              out_hidden, net->ppart, net->rpart);
+        else
+            ttt_job_kernel_h<false><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                               out_hidden, net->ppart, net->rpart);
+    } else {
+        const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
+        if (split_hidden)
+            ttt_job_kernel_w<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                               out_hidden, net->ppart, net->rpart);
+        else
+            ttt_job_kernel_w<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                out_hidden, net->ppart, net->rpart);
+    }
+}
+
+// split_hidden: the hidden rows read and written are the split images of a native move's workspace (TicTacToe)
+static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                           int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                           float* out_value, float* out_logits, float* out_value_raw, bool split_hidden) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
     if (batch == 0) return MZ_OK;
@@ -2485,13 +2510,8 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
         if (job_f32())
             ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
                                                                         action, out_hidden, net->ppart, net->rpart);
-        else if (job_rows32())
-            ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                                 bs, action, out_hidden, net->ppart,
-                                                                                 net->rpart);
         else
-            ttt_job_kernel_w<false><<<32 * (((batch + 63) / 64 + 7) / 8), kThreadsW, 0, st>>>(
-                net->ttt, batch, hidden_base, parent_block, bs, action, out_hidden, net->ppart, net->rpart);
+            launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
         ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
@@ -2509,6 +2529,13 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                                                                out_hidden, out_reward, out_value, out_logits, out_value_raw);
     }
     return launch_status("recurrent inference");
+}
+
+int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                       int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                       float* out_value, float* out_logits, float* out_value_raw) {
+    return infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward, out_value,
+                           out_logits, out_value_raw, false);
 }
 
 // Internal to the library (mz_pool_internal.h): the initial inference of a native move.  The move owns its hidden
@@ -2556,8 +2583,8 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
         return MZ_OK;
     }
     if (!fusable) {                                   // the same work as separate launches
-        int s = mz_infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward,
-                                   out_value, out_logits, nullptr);
+        int s = infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward,
+                                out_value, out_logits, nullptr, net->hidden_split);
         if (s != MZ_OK) return s;
         if (net->mid_event && net->kind != MZ_NET_TICTACTOE) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
         return with_select ? mz_step_logits(pool, out_logits, out_reward, out_value, parent_block, action)
@@ -2575,26 +2602,8 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
         ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
                                                                     (long)block_stride, action, out_hidden, net->ppart,
                                                                     net->rpart);
-    else if (job_rows32()) {
-        if (net->hidden_split)
-            ttt_job_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                                (long)block_stride, action, out_hidden,
-                                                                                net->ppart, net->rpart);
-        else
-            ttt_job_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base,
-                                                                                 parent_block, (long)block_stride, action,
-                                                                                 out_hidden, net->ppart, net->rpart);
-    } else {
-        const int gridw = 32 * (((batch + 63) / 64 + 7) / 8);
-        if (net->hidden_split)
-            ttt_job_kernel_w<true><<<gridw, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                (long)block_stride, action, out_hidden, net->ppart,
-                                                                net->rpart);
-        else
-            ttt_job_kernel_w<false><<<gridw, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                 (long)block_stride, action, out_hidden, net->ppart,
-                                                                 net->rpart);
-    }
+    else
+        launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)

@@ -34,9 +34,9 @@ def shard_bounds(total_games: int, rank: int, world: int):
 
 
 class LockstepSearch:
-    def __init__(self, config, network, num_trees: int, device=None, out=None):
+    def __init__(self, config, network, num_trees: int, device=None, out=None, lanes_per_tree: int = 0):
         """`out`: optional (visits, root_value, minmax, policy, action) tensors to write the results to (views of a
-        larger batch, see PipelinedSearch); allocated here when absent."""
+        larger batch, see PipelinedSearch); allocated here when absent.  `lanes_per_tree`: TreePool's (0 = its choice)."""
         self.config = config
         self.network = network
         g, m = config.game_config, config.mcts_config
@@ -47,7 +47,8 @@ class LockstepSearch:
             raise MuZeroError(f'network has {network.ACTION_SPACE_SIZE} actions, the game {self.A}')
         self.pool = TreePool(num_trees=self.T, num_actions=self.A, max_simulations=self.N,
                              num_players=g.num_players, discount=g.discount, default_value=m.default_value,
-                             known_bounds=None if kb is None else kb.endpoints(), device=self.device)
+                             known_bounds=None if kb is None else kb.endpoints(), device=self.device,
+                             lanes_per_tree=lanes_per_tree)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.hidden = torch.empty(self.N + 1, self.T, network.hidden_size, **f32)
         self.root_value_net = torch.empty(self.T, **f32)        # initial-inference value (unused by the search)

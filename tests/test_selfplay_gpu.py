@@ -250,6 +250,35 @@ def test_native_move_equals_python_driven_move():
     assert torch.allclose(decoded, hidden_a.double(), rtol=2.0 ** -20, atol=1e-9)
 
 
+@pytest.mark.parametrize('game', ['tictactoe', 'cartpole'])
+def test_native_move_with_unfused_tree_step(game):
+    """A pool whose lane count rules out the fused network + tree-step kernels: the native move then runs the network and
+    the tree step as separate launches -- on the same hidden workspace (TicTacToe: split images) -- and returns what the
+    default pool returns, bit for bit (lanes per tree do not change results, test_tree_gpu.py)."""
+    import torch
+    from muzero_amd.games import cartpole, tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[game]
+    T, N = 150, 10
+    config = mod.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights(game, 9))
+    A = config.game_config.action_space_size
+    g = torch.Generator(device='cuda').manual_seed(2)
+    if game == 'tictactoe':
+        obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    else:
+        obs = (torch.rand(T, 4, generator=g, device='cuda') * 2 - 1) * torch.tensor([2.4, 3.0, 0.2, 3.0], device='cuda')
+    noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    a = [x.clone() for x in LockstepSearch(config, net, num_trees=T).run(obs, noise, u, temp)]
+    other = {'tictactoe': 8, 'cartpole': 4}[game]
+    b = [x.clone() for x in LockstepSearch(config, net, num_trees=T, lanes_per_tree=other).run(obs, noise, u, temp)]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('lanes', [2, 3])
 def test_pipelined_lanes_equal_one_lockstep_search(lanes):
     """PipelinedSearch (games split into lanes on separate HIP streams) returns what one LockstepSearch over the same
