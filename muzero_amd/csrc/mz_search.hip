@@ -1,7 +1,7 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as ~2N+6 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as ~2N+8 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
@@ -21,7 +21,11 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         if (s_ != MZ_OK) return s_; \
     } while (0)
     MZ_TRY_(mz_pool_reset(pool));
-    // initial inference; from here to the end the hidden workspace is the network's
+    // initial inference; from here to the end (every exit, errors included) the hidden workspace is the network's
+    struct EndMove {
+        mz_net_t* net;
+        ~EndMove() { mz_net_end_move(net); }
+    } end_move{net};
     MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
     MZ_TRY_(mz_expand_roots_logits(pool, io->logits, io->legal, io->n_legal));
     MZ_TRY_(mz_add_root_noise(pool, io->noise, io->noise_frac));
@@ -39,7 +43,6 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
-    mz_net_end_move(net);
     MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
     if (io->out_action) MZ_TRY_(mz_select_action(pool, io->u, io->temperature, io->out_action));
 #undef MZ_TRY_
