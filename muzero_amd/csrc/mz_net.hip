@@ -150,6 +150,7 @@ struct TttDev {
     const float* pred_conv_s;
     const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
+    int job_cells[4][3];        // the cells of job j, -1 = none
     float dyn_reward_b, pred_value_b;
 };
 
@@ -1128,8 +1129,7 @@ __device__ __forceinline__ void mma_tile_h_plain(const _Float16* sA, const BFrag
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
 }
 
-// Initial inference, split-f16: the job kernel's grid and jobs (32 games x a group of cells; descriptors of kind 1 and 2
-// are the cells' Dense and prediction stages, the taps are skipped).  Per cell: representation Conv2D 3x3 same 3 -> 128
+// Initial inference, split-f16: the 32-row job kernel's grid and jobs (32 games x a group of cells, TttDev::job_cells).  Per cell: representation Conv2D 3x3 same 3 -> 128
 // relu on the VALU (K = 27, games/tictactoe.py:182), Dense 128 -> 128 relu = hidden[cell] (:184), and the cell's term
 // of the prediction conv (:201) accumulated over the job's cells: one partial per (game, job), so the head is the
 // recurrent one's.  SPLIT_IO: hidden leaves as split images (the workspace of a native move), else as f32.
@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     __shared__ __attribute__((aligned(16))) float sXF[ROWS * kLd];
     __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
     __shared__ float sObs[ROWS * 27];
+    __shared__ __attribute__((aligned(16))) float sConvW[27 * 128];      // the 3 -> 128 conv's weights, all nine taps
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1149,11 +1150,12 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
     const int row0 = rb * ROWS;
-    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
     for (int i = tid; i < ROWS * 27; i += kThreads) {
         const int b = row0 + i / 27;
         sObs[i] = b < B ? observation[(size_t)b * 27 + i % 27] : 0.f;
     }
+    for (int i = tid; i < 27 * 32; i += kThreads)
+        reinterpret_cast<float4*>(sConvW)[i] = reinterpret_cast<const float4*>(w.rep_conv)[i];
     BFrag bd;
     load_b(bd, w.rep_dense_h, lane, wave);           // the same Dense for every cell
     const int lrow = lane & 31, lcol = wave * 32 + 4 * (lane >> 5);     // transposed accumulators, see mma_block_h
@@ -1168,19 +1170,18 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     for (int r = 0; r < 16; ++r) accp[r] = 0.f;
     __syncthreads();
 #pragma unroll 1
-    for (int d = 0; d < d1; ++d) {
-        const int4 D = w.job_desc[dbase + d];
-        const int kind = __builtin_amdgcn_readfirstlane(D.x & 7), cell = __builtin_amdgcn_readfirstlane(D.y);
-        if (kind != 1) continue;                     // one pass per cell
+    for (int ci3 = 0; ci3 < 3; ++ci3) {
+        const int cell = w.job_cells[job][ci3];      // kernel argument: a scalar load
+        if (cell < 0) break;
         BFrag bp;
         load_b(bp, w.pred_conv_h + (size_t)cell * 16384, lane, wave);
         const int ci = cell / 3, cj = cell % 3;
         float4 s[4] = {cb, cb, cb, cb};
-#pragma unroll 1
+#pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
             if (ni < 0 || ni >= 3 || nj < 0 || nj >= 3) continue;
-            const float4* wt = reinterpret_cast<const float4*>(w.rep_conv + (size_t)t * 3 * 128) + c4;
+            const float4* wt = reinterpret_cast<const float4*>(sConvW + t * 3 * 128) + c4;
             const float4 w0 = wt[0], w1 = wt[32], w2 = wt[64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2183,6 +2184,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             }
         };
         for (int j = 0; j < 4; ++j) {
+            for (int ci = 0; ci < 3; ++ci) net->ttt.job_cells[j][ci] = kJobCells[j][ci];
             net->ttt.job_first[j] = (int)desc.size() / 4;
             for (int ci = 0; ci < 3; ++ci) {
                 const int c = kJobCells[j][ci];
