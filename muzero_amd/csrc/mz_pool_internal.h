@@ -29,3 +29,7 @@ struct mz_net;
 extern "C" int mz_net_begin_move(mz_net* net, int batch, const float* observation, float* hidden_block0, float* out_value,
                                  float* out_logits);
 extern "C" void mz_net_end_move(mz_net* net);
+
+// mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL), one launch
+extern "C" int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits, const int32_t* legal,
+                                     const int32_t* n_legal, const double* noise, double frac);

@@ -27,8 +27,7 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         ~EndMove() { mz_net_end_move(net); }
     } end_move{net};
     MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
-    MZ_TRY_(mz_expand_roots_logits(pool, io->logits, io->legal, io->n_legal));
-    MZ_TRY_(mz_add_root_noise(pool, io->noise, io->noise_frac));
+    MZ_TRY_(mz_expand_roots_noise(pool, io->logits, 1, io->legal, io->n_legal, io->noise, io->noise_frac));
     MZ_TRY_(mz_select(pool, io->parent_block, io->action));
     for (int s = 0; s < N; ++s) {
         const bool timed = ev && ev[4 * s];           // a simulation whose events are NULL is not timed
@@ -63,8 +62,7 @@ extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations,
         if (s_ != MZ_OK) return s_; \
     } while (0)
     MZ_TRY_(mz_pool_reset(pool));
-    MZ_TRY_(is_logits ? mz_expand_roots_logits(pool, policy, legal, n_legal) : mz_expand_roots(pool, policy, legal, n_legal));
-    if (noise) MZ_TRY_(mz_add_root_noise(pool, noise, noise_frac));
+    MZ_TRY_(mz_expand_roots_noise(pool, policy, is_logits, legal, n_legal, noise, noise_frac));
     MZ_TRY_(mz_select(pool, parent_block, action));
     for (int s = 1; s <= N; ++s) {
         const float* pol = policy + (size_t)s * TA;

@@ -121,10 +121,12 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev
     select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
 }
 
-// Root expansion (agent.py:154-160 on the root; positional priors, trap T5).
+// Root expansion (agent.py:154-160 on the root; positional priors, trap T5).  noise != NULL: add_exploration_noise
+// (agent.py:170-175) in the same pass, the arithmetic of root_noise_kernel on the prior just computed.
 template <int G, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, const float* pol, const int* legal,
-                                                                     const int* n_legal) {
+                                                                     const int* n_legal, const double* noise,
+                                                                     double frac) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const int A = p.A;
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
         slots[k].count = 0;
         slots[k].prior = pk;
         slots[k].act = a;
-        p.root_prior[(size_t)tree * A + k] = (double)pk;
+        const double rp = (double)pk;
+        p.root_prior[(size_t)tree * A + k] =
+            noise ? rp * (1 - frac) + noise[(size_t)tree * A + k] * frac : rp;     // agent.py:175 (fp64, uncontracted)
     }
     if (gl == 0) {
         p.n_root[tree] = n;
@@ -403,7 +407,8 @@ int check_launch(const char* what) {
     return MZ_OK;
 }
 
-int expand_roots_impl(mz_pool* pool, const float* pol, const int32_t* legal, const int32_t* n_legal, bool logits) {
+int expand_roots_impl(mz_pool* pool, const float* pol, const int32_t* legal, const int32_t* n_legal, bool logits,
+                      const double* noise = nullptr, double frac = 0.0) {
     MZ_REQUIRE(pool != nullptr, "pool is NULL");
     MZ_REQUIRE(pol != nullptr, "priors/logits is NULL");
     MZ_HIP(hipSetDevice(pool->device));
@@ -411,9 +416,11 @@ int expand_roots_impl(mz_pool* pool, const float* pol, const int32_t* legal, con
     dispatch_group(pool->G, [&](auto g) {
         constexpr int G = decltype(g)::value;
         if (logits)
-            expand_roots_kernel<G, true><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal);
+            expand_roots_kernel<G, true><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal, noise,
+                                                                                   frac);
         else
-            expand_roots_kernel<G, false><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal);
+            expand_roots_kernel<G, false><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal, noise,
+                                                                                    frac);
     });
     MZ_TRY(check_launch("expand_roots_kernel"));
     pool->blocks_in_use = 1;
@@ -609,6 +616,13 @@ int mz_expand_roots(mz_pool_t* pool, const float* priors, const int32_t* legal, 
 
 int mz_expand_roots_logits(mz_pool_t* pool, const float* logits, const int32_t* legal, const int32_t* n_legal) {
     return expand_roots_impl(pool, logits, legal, n_legal, true);
+}
+
+// Internal to the library (mz_pool_internal.h): mz_expand_roots[_logits] followed by mz_add_root_noise, as one launch.
+__attribute__((visibility("hidden"))) int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits,
+                                                                const int32_t* legal, const int32_t* n_legal,
+                                                                const double* noise, double frac) {
+    return expand_roots_impl(pool, pol, legal, n_legal, is_logits != 0, noise, frac);
 }
 
 int mz_add_root_noise(mz_pool_t* pool, const double* noise, double frac) {
