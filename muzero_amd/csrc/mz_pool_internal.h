@@ -33,3 +33,7 @@ extern "C" void mz_net_end_move(mz_net* net);
 // mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL), one launch
 extern "C" int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits, const int32_t* legal,
                                      const int32_t* n_legal, const double* noise, double frac);
+
+// mz_root_stats followed by mz_select_action, one launch
+extern "C" int mz_root_finish(mz_pool_t* pool, int32_t* visits, double* root_value, double* minmax, float* policy,
+                              const double* u, const double* temperature, int32_t* out_action);

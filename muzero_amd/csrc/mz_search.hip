@@ -42,8 +42,11 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
-    MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
-    if (io->out_action) MZ_TRY_(mz_select_action(pool, io->u, io->temperature, io->out_action));
+    if (io->out_action)
+        MZ_TRY_(mz_root_finish(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy, io->u,
+                               io->temperature, io->out_action));
+    else
+        MZ_TRY_(mz_root_stats(pool, io->out_visits, io->out_root_value, io->out_minmax, io->out_policy));
 #undef MZ_TRY_
     return MZ_OK;
 }

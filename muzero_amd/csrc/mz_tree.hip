@@ -198,10 +198,8 @@ __global__ void root_noise_kernel(PoolDev p, const double* noise, double frac) {
 
 // One wavefront per tree: the rows of visits / policy are cleared and the root's children scattered into them by all
 // 64 lanes (one lane per tree took 236 us at A = 362).
-__global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
-                                                        float* policy) {
-    const int tree = blockIdx.x, lane = threadIdx.x;
-    if (tree >= p.T) return;
+__device__ __forceinline__ void root_stats_tree(const PoolDev& p, int tree, int lane, int* visits, double* root_value,
+                                                double* minmax, float* policy) {
     const int A = p.A, n = p.n_root[tree];
     const int rc = p.root_count[tree];
     for (int a = lane; a < A; a += 64) {
@@ -227,16 +225,18 @@ __global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, 
         }
     }
 }
+__global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
+                                                        float* policy) {
+    if ((int)blockIdx.x < p.T) root_stats_tree(p, blockIdx.x, threadIdx.x, visits, root_value, minmax, policy);
+}
 
 // softmax_sample (agent.py:162-168) with CPython's random.choices arithmetic.  One wavefront per tree: the lanes read the
 // root's children and raise their counts to 1/t side by side (element-wise, so the values are those of a sequential
 // pass); the cumulative sums, whose order is part of the result, are lane 0's.
-__global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const double* u, const double* temperature,
-                                                           int* out_action) {
+__device__ __forceinline__ void select_action_tree(const PoolDev& p, int tree, int lane, const double* u,
+                                                   const double* temperature, int* out_action) {
     __shared__ double s_w[kMaxActions];
     __shared__ int s_act[kMaxActions];
-    const int tree = blockIdx.x, lane = threadIdx.x;
-    if (tree >= p.T) return;
     const int n = p.n_root[tree];
     if (n <= 0) {
         if (lane == 0) out_action[tree] = -1;
@@ -285,6 +285,18 @@ __global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const doub
         else break;
     }
     out_action[tree] = s_act[idx];
+}
+__global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const double* u, const double* temperature,
+                                                           int* out_action) {
+    if ((int)blockIdx.x < p.T) select_action_tree(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
+}
+// the end of a move in one launch: mz_root_stats, then mz_select_action
+__global__ __launch_bounds__(64) void root_finish_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
+                                                         float* policy, const double* u, const double* temperature,
+                                                         int* out_action) {
+    if ((int)blockIdx.x >= p.T) return;
+    root_stats_tree(p, blockIdx.x, threadIdx.x, visits, root_value, minmax, policy);
+    select_action_tree(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
 }
 
 __global__ void sum_counters_kernel(PoolDev p, long long* out2) {
@@ -690,6 +702,19 @@ int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature
     hipLaunchKernelGGL(select_action_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, u, temperature,
                        out_action);
     return check_launch("select_action_kernel");
+}
+
+// Internal to the library (mz_pool_internal.h): mz_root_stats followed by mz_select_action, as one launch.
+__attribute__((visibility("hidden"))) int mz_root_finish(mz_pool_t* pool, int32_t* visits, double* root_value,
+                                                         double* minmax, float* policy, const double* u,
+                                                         const double* temperature, int32_t* out_action) {
+    MZ_REQUIRE(pool != nullptr, "pool is NULL");
+    MZ_REQUIRE(u && temperature && out_action, "u, temperature and out_action must be non-NULL");
+    if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "root statistics before expand_roots");
+    MZ_HIP(hipSetDevice(pool->device));
+    hipLaunchKernelGGL(root_finish_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, visits, root_value,
+                       minmax, policy, u, temperature, out_action);
+    return check_launch("root_finish_kernel");
 }
 
 int mz_pool_counters(mz_pool_t* pool, int64_t* out4_host) {
