@@ -233,10 +233,13 @@ __global__ __launch_bounds__(64) void root_stats_kernel(PoolDev p, int* visits, 
 // softmax_sample (agent.py:162-168) with CPython's random.choices arithmetic.  One wavefront per tree: the lanes read the
 // root's children and raise their counts to 1/t side by side (element-wise, so the values are those of a sequential
 // pass); the cumulative sums, whose order is part of the result, are lane 0's.
+// MAXA: the LDS staging's capacity (>= the pool's action count); the small one keeps the workgroups of a narrow game
+// from being limited to three per CU by 48 KB of LDS each
+template <int MAXA>
 __device__ __forceinline__ void select_action_tree(const PoolDev& p, int tree, int lane, const double* u,
                                                    const double* temperature, int* out_action) {
-    __shared__ double s_w[kMaxActions];
-    __shared__ int s_act[kMaxActions];
+    __shared__ double s_w[MAXA];
+    __shared__ int s_act[MAXA];
     const int n = p.n_root[tree];
     if (n <= 0) {
         if (lane == 0) out_action[tree] = -1;
@@ -286,17 +289,20 @@ __device__ __forceinline__ void select_action_tree(const PoolDev& p, int tree, i
     }
     out_action[tree] = s_act[idx];
 }
+constexpr int kSmallA = 64;
+template <int MAXA>
 __global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const double* u, const double* temperature,
                                                            int* out_action) {
-    if ((int)blockIdx.x < p.T) select_action_tree(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
+    if ((int)blockIdx.x < p.T) select_action_tree<MAXA>(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
 }
 // the end of a move in one launch: mz_root_stats, then mz_select_action
+template <int MAXA>
 __global__ __launch_bounds__(64) void root_finish_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
                                                          float* policy, const double* u, const double* temperature,
                                                          int* out_action) {
     if ((int)blockIdx.x >= p.T) return;
     root_stats_tree(p, blockIdx.x, threadIdx.x, visits, root_value, minmax, policy);
-    select_action_tree(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
+    select_action_tree<MAXA>(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
 }
 
 __global__ void sum_counters_kernel(PoolDev p, long long* out2) {
@@ -699,8 +705,10 @@ int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature
     MZ_REQUIRE(u && temperature && out_action, "u, temperature and out_action must be non-NULL");
     if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "select_action before expand_roots");
     MZ_HIP(hipSetDevice(pool->device));
-    hipLaunchKernelGGL(select_action_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, u, temperature,
-                       out_action);
+    if (pool->dev.A <= kSmallA)
+        select_action_kernel<kSmallA><<<pool->dev.T, 64, 0, pool->stream>>>(pool->dev, u, temperature, out_action);
+    else
+        select_action_kernel<kMaxActions><<<pool->dev.T, 64, 0, pool->stream>>>(pool->dev, u, temperature, out_action);
     return check_launch("select_action_kernel");
 }
 
@@ -712,8 +720,12 @@ __attribute__((visibility("hidden"))) int mz_root_finish(mz_pool_t* pool, int32_
     MZ_REQUIRE(u && temperature && out_action, "u, temperature and out_action must be non-NULL");
     if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "root statistics before expand_roots");
     MZ_HIP(hipSetDevice(pool->device));
-    hipLaunchKernelGGL(root_finish_kernel, dim3(pool->dev.T), dim3(64), 0, pool->stream, pool->dev, visits, root_value,
-                       minmax, policy, u, temperature, out_action);
+    if (pool->dev.A <= kSmallA)
+        root_finish_kernel<kSmallA><<<pool->dev.T, 64, 0, pool->stream>>>(pool->dev, visits, root_value, minmax, policy, u,
+                                                                          temperature, out_action);
+    else
+        root_finish_kernel<kMaxActions><<<pool->dev.T, 64, 0, pool->stream>>>(pool->dev, visits, root_value, minmax, policy,
+                                                                              u, temperature, out_action);
     return check_launch("root_finish_kernel");
 }
 
