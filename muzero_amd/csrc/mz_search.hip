@@ -1,7 +1,7 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as ~2N+8 HIP launches on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as 2N+5 HIP launches (TicTacToe) on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
