@@ -193,6 +193,21 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                        int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
                        float* out_value, float* out_logits, float* out_value_raw);
 
+/* mz_infer_recurrent for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same kernels and bit-identical results as mz_infer_recurrent, but the kernels' scratch (TicTacToe:
+ * the prediction-conv partials and reward partial dots that the job kernel hands to the head kernel) is a static device
+ * array inside the library (MZ_NOALLOC_MAX_BATCH games, 4.76 MB per GPU, resolved once per device by mz_net_create)
+ * instead of hipMalloc'ed memory: the call reaches no hipMalloc / hipFree or allocating library routine.
+ *   - TicTacToe: batch > MZ_NOALLOC_MAX_BATCH is rejected with MZ_ERR_INVALID_ARG (split the batch, or use
+ *     mz_infer_recurrent); the CartPole kernels use no scratch and take any batch;
+ *   - every call on one GPU shares that GPU's array: two calls that overlap on one GPU (different streams or host
+ *     threads) race -- serialise them.  Nothing in the array has to be cleared between calls. */
+#define MZ_NOALLOC_MAX_BATCH 1024
+int mz_infer_recurrent_noalloc(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                               int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                               float* out_value, float* out_logits, float* out_value_raw);
+
 /* mz_infer_recurrent over all T trees of `pool` immediately followed by the tree update with its outputs:
  * mz_step_logits (with_select != 0: results land in parent_block / action, which are read first as this
  * simulation's leaf parents and actions) or mz_expand_backprop_logits (with_select == 0, the last simulation).

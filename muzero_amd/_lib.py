@@ -76,6 +76,8 @@ PROTOTYPES = {
                                                c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
     'mz_infer_recurrent': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_infer_recurrent_noalloc': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_env_ttt_reset': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_env_ttt_observe': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),

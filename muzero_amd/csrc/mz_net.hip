@@ -30,9 +30,41 @@
 #include <cstring>
 #include <new>
 #include <utility>
+#include <mutex>
 #include <vector>
 
+// ---- scratch of the allocation-free entry point (mz_infer_recurrent_noalloc) ------------------------------------------
+// The TicTacToe kernels hand the prediction-conv partials ([game][1152] floats, one 128-float slice per job) and the
+// reward-head partial dots ([game][9] floats) from the job kernel to the head kernel through device memory.  The ordinary
+// entry points keep that buffer in hipMalloc'ed memory sized to the largest batch seen (ensure_scratch); callers that must
+// not allocate get it from this array instead: kNoAllocMaxBatch games, 4.76 MB, held by every GPU the library runs on
+// until the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress -- the device address is
+// looked up once per device (scratch_for_device) and THAT pointer is what kernels and the head launch receive.
+constexpr int kNoAllocMaxBatch = 1024;
+constexpr size_t kScratchPpart = (size_t)kNoAllocMaxBatch * 1152;      // floats
+constexpr size_t kScratchRpart = (size_t)kNoAllocMaxBatch * 16;        // floats ([game][9], padded)
+static __device__ __align__(256) float scratch[kScratchPpart + kScratchRpart];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the CURRENT device `dev` (each GPU holds its own copy at its own address); looked up at
+// set-up (mz_net_create), never in the allocation-free entry point itself.
+int scratch_for_device(int dev, float** out) {
+    if (dev < 0 || dev >= kMaxDevices) return mz::fail(MZ_ERR_INVALID_ARG, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        MZ_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        if (!ptr) return mz::fail(MZ_ERR_HIP, "hipGetSymbolAddress(scratch) returned NULL");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MZ_OK;
+}
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -2031,6 +2063,7 @@ struct mz_net {
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
+    float* static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array (mz_infer_recurrent_noalloc)
     bool hidden_split = false;        // inside a native move: the hidden workspace holds split images (mz_net_begin_move)
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
 };
@@ -2291,6 +2324,13 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         net->cart.dyn_reward_b = dyn_reward_b[0];
     }
     hipError_t e = hipGetDevice(&net->device);
+    if (e == hipSuccess) {
+        const int st = scratch_for_device(net->device, &net->static_scratch);      // once per device, that device current
+        if (st != MZ_OK) {
+            delete net;
+            return st;
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&net->weights), pk.buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(net->weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -2469,31 +2509,33 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
 // The split-f16 TicTacToe job kernel of this build (64-row tiles, or 32-row ones under MZ_JOB_ROWS32), reading and writing
 // f32 hidden rows or, inside a native move, their split images.
 static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, const int* parent_block, long bs,
-                              const int* action, float* out_hidden, bool split_hidden) {
+                              const int* action, float* out_hidden, bool split_hidden, float* ppart, float* rpart) {
     hipStream_t st = net->stream;
     if (job_rows32()) {
         const int grid = 32 * (((batch + 31) / 32 + 7) / 8);
         if (split_hidden)
             ttt_job_kernel_h<true><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                              out_hidden, net->ppart, net->rpart);
+                                                              out_hidden, ppart, rpart);
         else
             ttt_job_kernel_h<false><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                               out_hidden, net->ppart, net->rpart);
+                                                               out_hidden, ppart, rpart);
     } else {
         const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
         if (split_hidden)
             ttt_job_kernel_w<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                               out_hidden, net->ppart, net->rpart);
+                                                               out_hidden, ppart, rpart);
         else
             ttt_job_kernel_w<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                out_hidden, net->ppart, net->rpart);
+                                                                out_hidden, ppart, rpart);
     }
 }
 
 // split_hidden: the hidden rows read and written are the split images of a native move's workspace (TicTacToe)
 static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
                            int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
-                           float* out_value, float* out_logits, float* out_value_raw, bool split_hidden) {
+                           float* out_value, float* out_logits, float* out_value_raw, bool split_hidden,
+                           float* ppart = nullptr, float* rpart = nullptr) {
+    // ppart / rpart: the TicTacToe kernels' scratch; NULL = the handle's own, (re)allocated here to fit the batch
     MZ_REQUIRE(net != nullptr, "net is NULL");
     MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
     if (batch == 0) return MZ_OK;
@@ -2506,17 +2548,21 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
     hipStream_t st = net->stream;
     const long bs = (long)block_stride;
     if (net->kind == MZ_NET_TICTACTOE) {
-        int s = ensure_scratch(net, batch);
-        if (s != MZ_OK) return s;
+        if (!ppart) {
+            int s = ensure_scratch(net, batch);
+            if (s != MZ_OK) return s;
+            ppart = net->ppart;
+            rpart = net->rpart;
+        }
         const int nrb32 = (batch + 31) / 32;
         if (job_f32())
             ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
-                                                                        action, out_hidden, net->ppart, net->rpart);
+                                                                        action, out_hidden, ppart, rpart);
         else
-            launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden);
+            launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden, ppart, rpart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
-        ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, net->ppart, net->rpart,
+        ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
                                                            out_reward, out_value, out_logits, out_value_raw);
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<false><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs,
@@ -2538,6 +2584,28 @@ int mz_infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_base, c
                        float* out_value, float* out_logits, float* out_value_raw) {
     return infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward, out_value,
                            out_logits, out_value_raw, false);
+}
+
+// mz_infer_recurrent for callers that must not allocate (HIP graph capture, serving loops): the TicTacToe kernels' scratch
+// is this device's copy of the file-scope `scratch` array, whose address mz_net_create looked up; no hipMalloc / hipFree
+// or allocating library routine is reached from here.  Nothing in the scratch has to start at zero: the job kernel
+// writes every partial the head kernel uses of an active row, and the head writes no output for the others.
+int mz_infer_recurrent_noalloc(mz_net_t* net, int32_t batch, const float* hidden_base, const int32_t* parent_block,
+                               int64_t block_stride, const int32_t* action, float* out_hidden, float* out_reward,
+                               float* out_value, float* out_logits, float* out_value_raw) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    float* ppart = nullptr;
+    float* rpart = nullptr;
+    if (net->kind == MZ_NET_TICTACTOE) {
+        MZ_REQUIRE(batch <= kNoAllocMaxBatch,
+                   "mz_infer_recurrent_noalloc: batch %d exceeds the static scratch (at most %d games per call); use "
+                   "mz_infer_recurrent or split the batch", batch, kNoAllocMaxBatch);
+        MZ_REQUIRE(net->static_scratch != nullptr, "static scratch was not resolved for device %d", net->device);
+        ppart = net->static_scratch;
+        rpart = net->static_scratch + kScratchPpart;
+    }
+    return infer_recurrent(net, batch, hidden_base, parent_block, block_stride, action, out_hidden, out_reward, out_value,
+                           out_logits, out_value_raw, false, ppart, rpart);
 }
 
 // Internal to the library (mz_pool_internal.h): the initial inference of a native move.  The move owns its hidden
@@ -2605,7 +2673,8 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
                                                                     (long)block_stride, action, out_hidden, net->ppart,
                                                                     net->rpart);
     else
-        launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split);
+        launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
+                          net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)
