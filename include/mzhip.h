@@ -131,6 +131,17 @@ int mz_root_stats(mz_pool_t* pool, int32_t* visits, double* root_value, double* 
  *   out_action  [T] i32. */
 int mz_select_action(mz_pool_t* pool, const double* u, const double* temperature, int32_t* out_action);
 
+/* Exact sampling weights for a temperature t.  softmax_sample raises the visit counts to 1/t with the HOST libm's pow
+ * (`count ** (1 / temperature)`, agent.py:167; t comes from visit_softmax_temperature_fn, config.py:153-157, or the
+ * --temperature override, agent_services.py:21-24), which a device pow does not reproduce bit for bit -- so the host
+ * tabulates it, like the exploration table of mz_pool_config_t:
+ *   weights_host: HOST pointer, max_simulations+1 doubles, weights_host[c] = (double)c ** (1/t) evaluated by the caller.
+ * mz_select_action and mz_search_move use the table for every tree whose temperature equals t (exact f64 match).
+ * A pool holds 8 tables; a ninth temperature replaces the oldest, registering the same t again overwrites its table.
+ * t = 0 (arg-max) and 1/t in {1, 2, 4} (exact products) need no table; any other unregistered temperature falls back
+ * to the device's pow (within 1 ulp of libm, not bit-exact).  Synchronises the pool's stream. */
+int mz_pool_set_temperature_table(mz_pool_t* pool, double temperature, const double* weights_host);
+
 /* Measurement counters, host output, synchronises the stream.
  *   out[0] simulations backed up (summed over trees), out[1] sum over those simulations of d = number of
  *   expanded nodes on the selection path (root included), out[2] select launches, out[3] backprop launches. */
@@ -143,6 +154,10 @@ int mz_pool_counters(mz_pool_t* pool, int64_t* out4_host);
 int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* out_num_children,
                        int32_t* actions, int32_t* count, double* value_sum, double* prior, float* reward,
                        int32_t* child);
+/* Inspection: the roots' fp32 priors as expand_node stored them, BEFORE the noise mix (NetworkOutput.masked_policy's
+ * k-th entry for the k-th listed child, agent.py:158-160; mz_pool_read_block reports the fp64 priors after it).
+ *   priors: HOST, A floats, the first *out_num_children valid.  Synchronises. */
+int mz_pool_read_root_priors(mz_pool_t* pool, int32_t tree, int32_t* out_num_children, float* priors);
 /* Number of blocks currently in use per tree (= simulations done + 1 after mz_expand_roots, else 0). */
 int mz_pool_num_blocks(mz_pool_t* pool);
 /* Device bytes held by the pool. */
@@ -253,7 +268,9 @@ typedef struct mz_move_io {
 } mz_move_io_t;
 
 /* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in
- * the loop, root statistics and action sampling -- about 2N+6 (TicTacToe) or 3N+6 launches on the stream, no host synchronisation. */
+ * the loop, root statistics and action sampling -- 2N+5 (TicTacToe) or N+4 (CartPole) launches on the stream, no host synchronisation.
+ * io is checked against the handles (MZ_ERR_INVALID_ARG): num_trees == the pool's, num_simulations <= its max_simulations,
+ * hidden_size and the action count == the network's, and pool, net and io->stream name one stream. */
 int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
 
 /* The tree half of one move against a network whose outputs are given: run_mcts (agent.py:198-211) with

@@ -56,9 +56,11 @@ PROTOTYPES = {
     'mz_step_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_root_stats': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_select_action': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_pool_set_temperature_table': (ctypes.c_int, [c_void_p, c_double, c_void_p]),
     'mz_pool_counters': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_pool_read_block': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),
+    'mz_pool_read_root_priors': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     'mz_pool_num_blocks': (ctypes.c_int, [c_void_p]),
     'mz_pool_bytes': (c_int64, [c_void_p]),
     'mz_net_num_weights': (c_int64, [c_int32]),

@@ -328,6 +328,7 @@ class MCTSAgent(Agent):
         search = self._search_of(node)
         t = self.config.visit_softmax_temperature_fn(num_moves=num_moves, training_steps=self.network.training_steps())
         u = random.random() if t != 0.0 else 0.0          # random.choices consumes exactly one random()
+        search.pool.set_temperature(t)                    # exact count ** (1/t) weights, tabulated by this host
         chosen = search.pool.select_action(self._dev([u], torch.float64), self._dev([t], torch.float64))
         return int(chosen[0].item())
 

@@ -1,4 +1,4 @@
-// Fused inference kernels for the two reference networks (gfx950, fp32-input MFMA).
+// Fused inference kernels for the reference's two networks (gfx950).
 //
 // Replaces, in the reference (file:line relative to /root/reference):
 //   Network.initial_inference / recurrent_inference     network.py:209-254
@@ -9,20 +9,20 @@
 //   CartPoleNetwork layer stacks                         games/cartpole.py:92-132
 //   the leaf.parent.hidden_state gather of run_mcts      agent.py:204
 //
-// Building block: gemm64<K>() -- a 256-thread workgroup multiplies a 64-row activation tile held in LDS
-// (row stride K+4 floats: ds_read_b128 conflict-free) by a [K][128] weight matrix streamed from L2 in a
-// fragment-ordered packing ([K/8][128][8], one coalesced 1-KiB load per wave per 8 k's), with
-// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain: results stay within 1e-5 of the fp64 oracle).  Each wave owns
-// 32 output columns x 64 rows (two 32x32 accumulators), so a weight fragment feeds two MFMAs.
+// Arithmetic: every 128 x 128 contraction runs on f16 MFMA with both f32 operands split in two halfs (v = h + l/2048,
+// "split-f16", see below): three exact f16 products per f32 product, f32 accumulation, results within 1e-5 of the fp64
+// oracle.  Only CartPole batches beyond kCart16MaxBatch take the older f32-MFMA row-tile kernel (cartpole_kernel).
 //
 // TicTacToe (hidden = 3x3x128):
-//   kernel A (per 64 games x 1 board cell): 3x3 `same` conv as up to 9 chained gemm64 over the neighbour cells'
-//     hidden rows, gathered straight from the [N+1][T][H] hidden tensor by parent block (no gather copy); the
-//     one-hot action planes collapse into a per-(action, cell) bias table; Dense 128->128; writes hidden',
-//     the reward-head partial dot and the prediction conv's per-cell partial product.
-//   kernel B (per 64 games): sums the nine partials, Dense 128->128, value/policy/reward heads.
-// CartPole (hidden = 128): one kernel per call, a chain of gemm64 (binary action plane -> bias vector),
-//   softmax over the 101-bin value support and support_to_scalar fused in the epilogue.
+//   job kernel (ttt_job_kernel_w, 64 games x a group of board cells of nearly equal cost): the 3x3 `same` conv as chained
+//     128x128 stages over the neighbour cells' hidden rows, gathered straight from the [N+1][T][H] hidden tensor by
+//     parent block (no gather copy); the one-hot action planes collapse into a per-(action, cell) bias table; Dense
+//     128->128; writes hidden', the reward-head partial dots and the prediction conv's partial product of its cells.
+//   head (ttt_head16, 16 games): sums the partials, Dense 128->128, value/policy/reward heads; inside a search it is
+//     one launch with the tree step of its games (ttt_head_step_kernel).
+// CartPole (hidden = 128): one kernel per call (cartpole16_kernel, 16 games per workgroup), six chained stages (binary
+//   action plane -> bias vector), softmax over the 101-bin value support and support_to_scalar in the epilogue; inside a
+//   search the same launch ends with the tree step of its games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
 #include <cmath>
@@ -157,322 +157,36 @@ __device__ __forceinline__ float dot32x4(const float* h, const float* wv) {
 struct TttDev {
     const float* rep_conv;      // [9 taps][3][128] (Keras order)
     const float* rep_conv_b;    // [128]
-    const float* rep_dense_p;   // packed [16][128][8]
     const float* rep_dense_b;
-    const float* dyn_conv_p;    // [9 taps] x packed [16][128][8] (hidden channels 0..127)
     const float* dyn_actbias;   // [9 actions][9 cells][128]: conv bias + sum of the action plane's valid taps
-    const float* dyn_dense_p;
     const float* dyn_dense_b;
     const float* dyn_reward_w;  // [1152]
-    const float* pred_conv_p;   // [9 cells] x packed [16][128][8]
     const float* pred_conv_b;
-    const float* pred_dense_p;
+    const float* pred_dense_p;  // split-f16 fragments (Packer::add_split16)
     const float* pred_dense_b;
-    const float* pred_value_w;  // [128]
-    const float* pred_policy_w; // [9][128]
-    const float* pred_policy_b; // [9]
     const float* pred_head_p;   // split-f16 fragments (Packer::add_split16): column 0 = value head, 1..9 = policy heads
     const float* pred_head_b;   // [16]: value bias, 9 policy biases, zeros
-    const float* dyn_conv_h;    // the three GEMM operands of the job kernel again, as split-f16 fragments (pack_split_f16)
-    const float* dyn_dense_h;
-    const float* pred_conv_h;
-    const float* rep_dense_h;
-    const float* dyn_conv_s;    // and as fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16): ttt_job_kernel_w
-    const float* dyn_dense_s;
-    const float* pred_conv_s;
-    const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel)
+    const float* pred_conv_h;   // [9 cells] x split-f16 fragments for v_mfma_f32_32x32x16_f16 (Packer::add_split_f16):
+    const float* rep_dense_h;   //   the initial-inference kernel's operands
+    const float* dyn_conv_s;    // [9 taps] x split-f16 fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16):
+    const float* dyn_dense_s;   //   the job kernel's operands (hidden channels 0..127 of the conv)
+    const float* pred_conv_s;   // [9 cells]
+    const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel_w)
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     int job_cells[4][3];        // the cells of job j, -1 = none
     float dyn_reward_b, pred_value_b;
 };
 
-__constant__ int kCellOrder[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // heaviest (9 taps) first, corners (4 taps) last
-
-// Initial inference on f32 MFMAs (MZ_JOB_F32 comparison path; the product path is ttt_initial_kernel_h): one workgroup
-// per (cell, 32*MT games).  grid = 9 * ceil(B / (32*MT)); block = 256.
-template <int MT>
-__global__ __launch_bounds__(kThreads) void ttt_cell_kernel(TttDev w, int B, const float* __restrict__ observation,
-                                                            float* __restrict__ out_hidden, float* __restrict__ ppart) {
-    constexpr int ROWS = 32 * MT;
-    __shared__ __attribute__((aligned(16))) float sBuf[2][ROWS * kLd];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + ROWS - 1) / ROWS;
-    const int cell = kCellOrder[blockIdx.x / nrb];
-    const int row0 = (blockIdx.x % nrb) * ROWS;
-    const int ci = cell / 3, cj = cell % 3;
-
-    BFrag bcur, bnext;
-    load_b(bcur, w.rep_dense_p, lane, wave);
-    f32x16 acc[MT];
-    float* sX = sBuf[0];
-    float* sH = sBuf[1];
-    {
-        // representation Conv2D 3x3 same, 3 -> 128, relu (games/tictactoe.py:182): K = 27, done on the VALU
-        float* sObs = sBuf[1];           // [ROWS][27]
-        for (int i = tid; i < ROWS * 27; i += kThreads) {
-            const int b = row0 + i / 27;
-            sObs[i] = b < B ? observation[(size_t)b * 27 + (i % 27)] : 0.f;
-        }
-        __syncthreads();
-        const int n = tid & 127;
-        float wreg[27];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
-            const bool ok = ni >= 0 && ni < 3 && nj >= 0 && nj < 3;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) wreg[t * 3 + ch] = ok ? w.rep_conv[(t * 3 + ch) * 128 + n] : 0.f;
-        }
-        const float bn = w.rep_conv_b[n];
-        for (int r = tid >> 7; r < ROWS; r += 2) {
-            float s = bn;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ni = ci + t / 3 - 1, nj = cj + t % 3 - 1;
-                if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) {
-                    const float* o = sObs + r * 27 + (ni * 3 + nj) * 3;
-                    s += o[0] * wreg[t * 3] + o[1] * wreg[t * 3 + 1] + o[2] * wreg[t * 3 + 2];
-                }
-            }
-            sX[r * kLd + n] = fmaxf(s, 0.f);
-        }
-        load_b(bnext, w.pred_conv_p + (size_t)cell * 16384, lane, wave);
-        __syncthreads();
-    }
-
-    // Dense 128 -> 128, relu = the hidden state of this cell (games/tictactoe.py:184)
-    zero_acc(acc);
-    mma_tile<MT>(sX, bcur, acc, lane);
-    {
-        const int n = wave * 32 + (lane & 31);
-        const float bn = w.rep_dense_b[n];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(m, r, lane);
-                const float v = fmaxf(acc[m][r] + bn, 0.f);
-                sH[row * kLd + n] = v;
-                if (row0 + row < B) out_hidden[(size_t)(row0 + row) * 1152 + cell * 128 + n] = v;
-            }
-    }
-    __syncthreads();
-    // prediction Conv2D 3x3 valid over the 3x3 board = sum over cells of hidden[cell] @ W[cell]: this cell's term
-    zero_acc(acc);
-    mma_tile<MT>(sH, bnext, acc, lane);
-    {
-        const int n = wave * 32 + (lane & 31);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(m, r, lane);
-                if (row0 + row < B) ppart[((size_t)(row0 + row) * 9 + cell) * 128 + n] = acc[m][r];
-            }
-    }
-}
-
-// acc += sA[32][128] * W held in b.  As soon as the four MFMAs of k-step kb have consumed b.v[kb], that register is
-// re-loaded with the NEXT stage's weights (in-place ring: every load gets a whole stage, ~4096 MFMA cycles, to land,
-// and there is one weight set in registers instead of two), and the next activation tile is requested on the first
-// k-steps.  Issuing a stage's 80 KB up front instead stalls every wave of the workgroup on the vector-memory path.
-template <int KB>
-__device__ __forceinline__ void mma_step_pf(const float* ap, float4 (&af)[3], BFrag& b, f32x16& acc,
-                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
-                                            float4 (&stg)[4]) {
-    // LDS fragment ring, two k-steps ahead: the read issued here is consumed 8 MFMAs (512 cycles) later
-    if (KB + 2 < 16) af[(KB + 2) % 3] = *reinterpret_cast<const float4*>(ap + (KB + 2) * 8);
-    const float4 a = af[KB % 3];
-    const float4 bv = b.v[KB];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc, 0, 0, 0);
-    b.v[KB] = wnext[KB * 256];
-    if (KB < 4) stg[KB] = *reinterpret_cast<const float4*>(sptr[KB] + src);
-    // pin the interleave (hipcc otherwise sinks all 20 loads behind the last MFMA, right in front of the epilogue
-    // that waits for them): one LDS fragment read, 4 MFMA, then this k-step's VMEM reads
-    if (KB + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if (KB < 4)
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-    else
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-}
-
-template <int... KB>
-__device__ __forceinline__ void mma_steps_pf(std::integer_sequence<int, KB...>, const float* ap, float4 (&af)[3], BFrag& b,
-                                             f32x16& acc, const float4* __restrict__ wnext,
-                                             const float* const (&sptr)[4], int src, float4 (&stg)[4]) {
-    (mma_step_pf<KB>(ap, af, b, acc, wnext, sptr, src, stg), ...);
-}
-
-__device__ __forceinline__ void mma_tile_pf(const float* sA, BFrag& b, f32x16& acc, int lane,
-                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
-                                            float4 (&stg)[4]) {
-    const float* ap = sA + (lane & 31) * kLd + 4 * (lane >> 5);
-    float4 af[3];
-    af[0] = *reinterpret_cast<const float4*>(ap);
-    af[1] = *reinterpret_cast<const float4*>(ap + 8);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two ring-priming reads come first
-    mma_steps_pf(std::make_integer_sequence<int, 16>{}, ap, af, b, acc, wnext, sptr, src, stg);
-}
-
-// Recurrent inference, kernel A', uniform-cost jobs.  A job = 32 games x a group of board cells chosen so that every
-// workgroup runs 16-18 GEMM stages: {centre, corner 0} = 11+6, {edges 1,3} = 8+8, {edges 5,7} = 8+8,
-// {corners 2,6,8} = 6+6+6 (a cell costs its valid conv taps + Dense + prediction-conv term).  4096 games -> 512 jobs
-// = two per CU on 256 CUs, all finishing together (the per-cell grid left a 45-us tail of corner cells).
-// Stage s multiplies with the weights and the tile requested during stage s-1.
-// grid = 8 * 4 * ceil(ceil(B/32) / 8): block b -> XCD label x = b%8, i = b/8, job = i%4, row block = (i/4)*8 + x, so
-// the four jobs of a row block share an L2 (speed only).
-__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel(TttDev w, int B, const float* __restrict__ in_base,
-                                                              const int* __restrict__ parent_block, long block_stride,
-                                                              const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                              float* __restrict__ ppart, float* __restrict__ rpart) {
-    constexpr int ROWS = 32;
-    __shared__ __attribute__((aligned(16))) float sTile[2][ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sX[ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sH[ROWS * kLd];
-    __shared__ long sRowOff[ROWS];
-    __shared__ int sAct[ROWS];
-    __shared__ int4 sDesc[24];                       // this job's stage descriptors (LDS: keeps them off the vmcnt queue)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + ROWS - 1) / ROWS;
-    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    // blocks b and b+256 tend to share a CU: rotate the job by two there so a 17/18-stage job meets a 16-stage one
-    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
-    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
-    const int row0 = rb * ROWS;
-    const int dbase = w.job_first[job], d0 = 0, d1 = w.job_first[job + 1] - dbase;
-    const int n = wave * 32 + (lane & 31);
-    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_p) + n * 2 + (lane >> 5);   // + weights offset / 4
-
-    BFrag bw;
-    const int4 D0 = w.job_desc[dbase];
-    if (tid >= 64 && tid < 64 + d1) sDesc[tid - 64] = w.job_desc[dbase + tid - 64];
-    load_b(bw, w.dyn_conv_p + (size_t)D0.z * 16384, lane, wave);
-    if (tid < ROWS) {
-        const int b = row0 + tid;
-        long off = -1;
-        int a = 0;
-        if (b < B) {
-            const int pb = parent_block ? parent_block[b] : 0;
-            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-            a = action[b];
-            if (a < 0 || a > 8) a = 0;
-        }
-        sRowOff[tid] = off;
-        sAct[tid] = a;
-    }
-    __syncthreads();
-    const float* sptr[4];
-    unsigned svalid = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-        const long off = sRowOff[r];
-        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
-        if (off >= 0) svalid |= 1u << i;
-    }
-    float4 stg[4];
-    auto commit = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            const bool ok = (svalid >> i) & 1u;
-            *reinterpret_cast<float4*>(buf + r * kLd + c4 * 4) =
-                make_float4(ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f);
-        }
-    };
-    // LDS tile -> global rows (stride `ld` floats), 16-B coalesced, skipped rows masked
-    auto copy_out = [&](const float* sSrc, float* dst, int ld) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            if ((svalid >> i) & 1u)
-                *reinterpret_cast<float4*>(dst + (size_t)(row0 + r) * ld + c4 * 4) =
-                    *reinterpret_cast<const float4*>(sSrc + r * kLd + c4 * 4);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
-    commit(sTile[0]);
-    __syncthreads();
-
-    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-    int buf = 0;
-#pragma unroll 1
-    for (int d = d0; d < d1; ++d) {
-        const int4 Dc = sDesc[d];
-        const bool has_next = d + 1 < d1;
-        const int4 Dn = sDesc[has_next ? d + 1 : d];
-        const int kind = __builtin_amdgcn_readfirstlane(Dc.x & 7), cell = __builtin_amdgcn_readfirstlane(Dc.y);
-        const int nkind = __builtin_amdgcn_readfirstlane(Dn.x & 7);
-        const bool first_tap = __builtin_amdgcn_readfirstlane(Dc.x & 8) != 0, last_tap = __builtin_amdgcn_readfirstlane(Dc.x & 16) != 0;
-        const int ntap = __builtin_amdgcn_readfirstlane(Dn.z), ncell = __builtin_amdgcn_readfirstlane(Dn.y);
-        const int nsrc = __builtin_amdgcn_readfirstlane(Dn.w);
-        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
-        const float* wn = nkind == 0 ? w.dyn_conv_p + (size_t)ntap * 16384
-                        : nkind == 1 ? w.dyn_dense_p : w.pred_conv_p + (size_t)ncell * 16384;
-        const bool gather = has_next && nkind == 0;
-        const float* sA = kind == 0 ? sTile[buf] : kind == 1 ? sX : sH;
-        if (kind == 1 || first_tap) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-        float ab[16];
-        if (kind == 0 && last_tap) {
-            // last tap of a cell: request conv bias + action-plane bias of each accumulator row now, so the loads
-            // land under the MFMAs (action planes of the one-hot encoder are constant per cell: network.py:14-40)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[r] = w.dyn_actbias[(sAct[acc_row(0, r, lane)] * 9 + cell) * 128 + n];
-        }
-        if (kind == 2) acc = accp;          // one call site: the prediction partial rides in acc for its stage
-        mma_tile_pf(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_p) / 4, sptr, gather ? nsrc * 128 : 0, stg);
-        if (kind == 2) accp = acc;
-        if (kind == 0) {
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + ab[r], 0.f);
-            }
-            if (gather) commit(sTile[buf ^ 1]);
-            __syncthreads();
-            if (gather) buf ^= 1;
-        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
-            const float bn = w.dyn_dense_b[n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sH[acc_row(0, r, lane) * kLd + n] = fmaxf(acc[r] + bn, 0.f);
-            __syncthreads();
-            copy_out(sH, out_hidden + cell * 128, 1152);
-            if (tid < ROWS * 4) {                  // reward head partial (games/tictactoe.py:193-195)
-                const int row = tid >> 2, q = tid & 3;
-                const float sdot = dot32x4(sH + row * kLd + q * 32, w.dyn_reward_w + cell * 128 + q * 32);
-                if (q == 0 && sRowOff[row] >= 0) rpart[(size_t)(row0 + row) * 9 + cell] = sdot;
-            }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
-            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sX[acc_row(0, r, lane) * kLd + n] = accp[r];
-            }
-            if (gather) commit(sTile[buf ^ 1]);
-            __syncthreads();
-            if (gather) buf ^= 1;
-            if (!has_next) copy_out(sX, ppart + job * 128, 1152);
-        }
-    }
-}
-
-// ---- the same job kernel on split-f16 MFMA ---------------------------------------------------------------------------
+// ---- split-f16 MFMA --------------------------------------------------------------------------------------------------
 // An f32 value v is carried as two halfs, h = f16(v) and l = f16((v - h) * 2048): v = h + l/2048 to 22 mantissa bits.
 // A product a*b is then ah*bh + (ah*bl + al*bh)/2048 (+ al*bl/2^22, dropped: 2.4e-7 relative), every term an exact
 // f16 x f16 product accumulated in f32 by v_mfma_f32_32x32x16_f16.  Three of those cover 16 k's in 3 x 32 cycles; the
 // f32 MFMA takes 8 x 64 for the same 16 k's.  Measured against the fp64 oracle the outputs differ by ~1e-7, inside
-// the 1e-5 the f32 kernel is held to (tests/test_net_gpu.py) and no worse than f32 accumulation itself.
-// Operand images: weights pre-split on the host (Packer::add_split_f16, same bytes and the same register ring as the
-// f32 fragments); activation tiles in LDS as [row][128 h | 128 l] halfs on the f32 tile's 528-byte row stride, so the
-// fragment reads keep the f32 kernel's conflict-free geometry.
+// the 1e-5 an f32 kernel is held to (tests/test_net_gpu.py) and no worse than f32 accumulation itself.
+// Operand images: weights pre-split on the host (Packer::add_split16 / add_split_f16); activation tiles in LDS as
+// [row][128 h | 128 l] halfs.
+// Domain: |v| <= 65504 for every weight and activation (f16's largest finite value; the conversions saturate there),
+// checked for weights by mz_net_create and for activations by the kernels (mz_net_status).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
@@ -505,331 +219,13 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l) 
     l = make_uint2(lw[0], lw[1]);
 }
 
-// One 16-k block of a stage: acc += bh*ah, acc2 += bl*ah + bh*al (a = activations, b = weights).  The block's two weight registers are re-loaded with
-// the NEXT stage's fragments right after (in-place ring), the activation fragments are read two blocks ahead, and the
-// next tile's gather rides on the first four blocks.
-template <int T>
-__device__ __forceinline__ void mma_block_h(const _Float16* ap, float4 (&af)[3][2], BFrag& b, f32x16& acc, f32x16& acc2,
-                                            const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
-                                            float4 (&stg)[4]) {
-    if (T + 2 < 8) {
-        af[(T + 2) % 3][0] = *reinterpret_cast<const float4*>(ap + (T + 2) * 16);
-        af[(T + 2) % 3][1] = *reinterpret_cast<const float4*>(ap + 128 + (T + 2) * 16);
-    }
-    const f16x8 ah = __builtin_bit_cast(f16x8, af[T % 3][0]), al = __builtin_bit_cast(f16x8, af[T % 3][1]);
-    const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * T]), bl = __builtin_bit_cast(f16x8, b.v[2 * T + 1]);
-    // weights as the row operand: the product comes out transposed, a lane holds for ITS tile row (lane % 32) the
-    // columns 8 q + 4 (lane / 32) + {0..3} of the wave's 32 in registers 4 q + {0..3} -- runs of four consecutive columns,
-    // which is what the epilogues' packed splits and 8-byte stores want
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc2, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc2, 0, 0, 0);
-    b.v[2 * T] = wnext[(2 * T) * 256];
-    b.v[2 * T + 1] = wnext[(2 * T + 1) * 256];
-    if (T >= 6) {                                   // the tile two stages ahead, requested once stg has been committed
-        stg[2 * (T - 6)] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6)] + src);
-        stg[2 * (T - 6) + 1] = *reinterpret_cast<const float4*>(sptr[2 * (T - 6) + 1] + src);
-    }
-    // pin the interleave: this block's LDS fragment reads, its three MFMAs, then its VMEM reads
-    if (T + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, T >= 6 ? 4 : 2, 0);
-}
-
-template <int... T>
-__device__ __forceinline__ void mma_blocks_h(std::integer_sequence<int, T...>, const _Float16* ap, float4 (&af)[3][2],
-                                             BFrag& b, f32x16& acc, f32x16& acc2, const float4* __restrict__ wnext,
-                                             const float* const (&sptr)[4], int src, float4 (&stg)[4]) {
-    (mma_block_h<T>(ap, af, b, acc, acc2, wnext, sptr, src, stg), ...);
-}
-
-// acc += sA[32][128] * W (both split); returns with the cross terms folded in.  `mid` runs between the fourth and the
-// fifth block: the caller commits the tile gathered during the previous stage there, under this stage's MFMAs.
-template <typename Mid>
-__device__ __forceinline__ void mma_tile_h(const _Float16* sA, BFrag& b, f32x16& acc, int lane,
-                                           const float4* __restrict__ wnext, const float* const (&sptr)[4], int src,
-                                           float4 (&stg)[4], Mid&& mid) {
-    const _Float16* ap = sA + (lane & 31) * kLdH + 8 * (lane >> 5);
-    float4 af[3][2];
-    af[0][0] = *reinterpret_cast<const float4*>(ap);
-    af[0][1] = *reinterpret_cast<const float4*>(ap + 128);
-    af[1][0] = *reinterpret_cast<const float4*>(ap + 16);
-    af[1][1] = *reinterpret_cast<const float4*>(ap + 128 + 16);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the ring-priming reads come first
-    f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    mma_blocks_h(std::integer_sequence<int, 0, 1, 2, 3>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
-    mid();
-    mma_blocks_h(std::integer_sequence<int, 4, 5, 6, 7>{}, ap, af, b, acc, acc2, wnext, sptr, src, stg);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r] * kUnsplit;
-}
-
-// Same jobs, stages, grid and outputs as ttt_job_kernel.  SPLIT_IO: the hidden-state rows in HBM (gathered parents and
-// the rows written) are split images ([128 h | 128 l] halfs per cell, the bytes of 128 floats) instead of floats -- the
-// workspace of a native move (mz_search_move), where nobody else reads them: a gathered row is then copied into the tile
-// as it is, instead of being split by every one of the up to nine stages that read it.
-template <bool SPLIT_IO>
-__global__ __launch_bounds__(kThreads, 2) void ttt_job_kernel_h(TttDev w, int B, const float* __restrict__ in_base,
-                                                                const int* __restrict__ parent_block, long block_stride,
-                                                                const int* __restrict__ action,
-                                                                float* __restrict__ out_hidden, float* __restrict__ ppart,
-                                                                float* __restrict__ rpart) {
-    constexpr int ROWS = 32;
-    __shared__ __attribute__((aligned(16))) float sTileF[2][ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sXF[ROWS * kLd];
-    __shared__ __attribute__((aligned(16))) float sHF[ROWS * kLd];
-    __shared__ long sRowOff[ROWS];
-    __shared__ int sAct[ROWS];
-    __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // conv bias + action-plane bias of the current cell,
-                                                     // per action; [9*128..]: the cell's 128 reward-head weights;
-                                                     // [10*128..]: the dense layer's bias
-    __shared__ float sRew[4 * ROWS];                 // reward-head partials of the four waves' column ranges
-    auto tile = [&](int b) { return reinterpret_cast<_Float16*>(sTileF[b]); };
-    _Float16* sX = reinterpret_cast<_Float16*>(sXF);
-    _Float16* sH = reinterpret_cast<_Float16*>(sHF);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + ROWS - 1) / ROWS;
-    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
-    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
-    const int row0 = rb * ROWS;
-    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
-    const int n = wave * 32 + (lane & 31);
-    const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_h) + n * 2 + (lane >> 5);   // + weights offset / 4
-
-    // Every load in the loop body is issued BEFORE the stage's weight loads: vmcnt is in-order, so a load issued in an
-    // epilogue would have to drain the next stage's twenty loads behind which nothing else needs to wait.
-    if (tid < 128) sBias[10 * 128 + tid] = w.dyn_dense_b[tid];
-    BFrag bw;
-    // stage descriptors: uniform addresses in the constant address space = scalar loads into SGPRs, one stage ahead of
-    // their use (nothing to broadcast, nothing on the vector memory or LDS queues)
-    typedef int __attribute__((ext_vector_type(4))) Desc;      // .x kind | flags, .y cell, .z tap, .w source cell
-    typedef const __attribute__((address_space(4))) Desc* DescPtr;
-    const DescPtr desc = (DescPtr)w.job_desc + dbase;
-    const Desc D0 = desc[0];
-    load_b(bw, w.dyn_conv_h + (size_t)D0.z * 16384, lane, wave);
-    if (tid < ROWS) {
-        const int b = row0 + tid;
-        long off = -1;
-        int a = 0;
-        if (b < B) {
-            const int pb = parent_block ? parent_block[b] : 0;
-            if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-            a = action[b];
-            if (a < 0 || a > 8) a = 0;
-        }
-        sRowOff[tid] = off;
-        sAct[tid] = a;
-    }
-    __syncthreads();
-    const float* sptr[4];
-    unsigned svalid = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-        const long off = sRowOff[r];
-        sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
-        if (off >= 0) svalid |= 1u << i;
-    }
-    float4 stg[4];
-    // gathered f32 rows -> split tile: 4 h halfs and 4 l halfs per thread and i, one 8-byte store each
-    auto commit = [&](_Float16* buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-            const bool ok = (svalid >> i) & 1u;
-            if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
-                *reinterpret_cast<float4*>(buf + r * kLdH + c4 * 8) = ok ? stg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                continue;
-            }
-            const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
-            // h by the packed round-toward-zero conversion (v - h is exact whatever the rounding of h; the residual is
-            // then < 1 ulp of h instead of half of one, still 21 bits in all), l likewise
-            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-            const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
-            const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
-            const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * kSplit, (v[1] - (float)h01[1]) * kSplit));
-            const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * kSplit, (v[3] - (float)h23[1]) * kSplit));
-            f16x4 h, l;
-            h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
-            l[0] = l01[0]; l[1] = l01[1]; l[2] = l23[0]; l[3] = l23[1];
-            *reinterpret_cast<f16x4*>(buf + r * kLdH + c4 * 4) = h;
-            *reinterpret_cast<f16x4*>(buf + r * kLdH + 128 + c4 * 4) = l;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
-    commit(tile(0));
-    {   // stage 1's tile, if it gathers one, is on its way while stage 0 starts
-        const Desc D1 = desc[d1 > 1 ? 1 : 0];
-        const int src1 = (d1 > 1 && (D1.x & 7) == 0) ? D1.w * 128 : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src1);
-    }
-    __syncthreads();
-
-    // rows with an output (game < B and a parent): one bit per row
-    const unsigned rowmask = (unsigned)__ballot(sRowOff[lane & 31] >= 0);
-    // the accumulators are transposed (mma_block_h): this lane's tile row, its action, and its first column
-    const int lrow = lane & 31, lcol = wave * 32 + 4 * (lane >> 5);
-    const bool lrow_ok = (rowmask >> lrow) & 1u;
-    const int lact = sAct[lrow];
-    f32x16 acc, accp;                                // accp: prediction-conv partial, summed over the job's cells
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-    int buf = 0;
-    Desc Dc = D0, Dn = desc[d1 > 1 ? 1 : 0], Dn2 = desc[d1 > 2 ? 2 : 0];
-    MZ_TRACE_DECL;
-    MZ_TRACE_NW(0);                                  // prologue
-#pragma unroll 1
-    for (int d = 0; d < d1; ++d) {
-        const bool has_next = d + 1 < d1;
-        const bool gather2 = d + 2 < d1 && (Dn2.x & 7) == 0;
-        const int nsrc2 = Dn2.w;
-        const int kind = Dc.x & 7, cell = Dc.y;
-        const int nkind = has_next ? Dn.x & 7 : kind;
-        const bool first_tap = (Dc.x & 8) != 0, last_tap = (Dc.x & 16) != 0;
-        const int ntap = has_next ? Dn.z : Dc.z, ncell = has_next ? Dn.y : Dc.y;
-        // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
-        const float* wn = nkind == 0 ? w.dyn_conv_h + (size_t)ntap * 16384
-                        : nkind == 1 ? w.dyn_dense_h : w.pred_conv_h + (size_t)ncell * 16384;
-        const bool gather = has_next && nkind == 0;
-        const _Float16* sA = kind == 0 ? tile(buf) : kind == 1 ? sX : sH;
-        if (kind == 1 || first_tap) {
-            asm volatile("");                   // a uniform branch, not thirty-two selects per stage
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-        float bt[5];
-        if (kind == 0 && first_tap) {
-            // first tap of a cell: its bias table (conv bias + the action plane's valid taps: the one-hot encoder's
-            // planes are constant per cell, network.py:14-40) for all nine actions, requested ahead of this stage's
-            // weight loads and parked in LDS at the end of the stage; the last tap's epilogue reads it from there
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int idx = tid + kThreads * i;
-                bt[i] = idx < 9 * 128 ? w.dyn_actbias[((idx >> 7) * 9 + cell) * 128 + (idx & 127)]
-                                      : w.dyn_reward_w[cell * 128 + (idx & 127)];      // idx in [1152, 1280)
-            }
-        }
-        if (kind == 2) {                    // one call site: the prediction partial rides in acc for its stage
-            asm volatile("");
-            acc = accp;
-        }
-        MZ_TRACE_NW(1);                              // stage set-up
-        // the next stage's tile (requested at the end of the previous stage) is split and written to LDS under this
-        // stage's MFMAs; the tile after it is requested at the end of this stage
-        mma_tile_h(sA, bw, acc, lane, wlane + (wn - w.dyn_conv_h) / 4, sptr, gather2 ? nsrc2 * 128 : 0, stg, [&] {
-            if (gather) commit(tile(buf ^ 1));
-        });
-        MZ_TRACE_NW(2);                              // MFMA section
-        // the descriptor three stages on, used from the next iteration: requested here, after the MFMA section (a scalar
-        // load in flight turns every LDS wait into a wait for everything), and back long before the stage's barrier
-        __builtin_amdgcn_sched_barrier(0);
-        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];
-        if (kind == 2) {
-            asm volatile("");
-            accp = acc;
-        }
-        if (kind == 0) {
-            if (first_tap) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int idx = tid + kThreads * i;
-                    sBias[idx] = bt[i];
-                }
-            }
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bq = *reinterpret_cast<const float4*>(sBias + lact * 128 + lcol + 8 * q);
-                    const float v[4] = {fmaxf(acc[4 * q] + bq.x, 0.f), fmaxf(acc[4 * q + 1] + bq.y, 0.f),
-                                        fmaxf(acc[4 * q + 2] + bq.z, 0.f), fmaxf(acc[4 * q + 3] + bq.w, 0.f)};
-                    uint2 h, l;
-                    split4(v, h, l);
-                    *reinterpret_cast<uint2*>(sX + lrow * kLdH + lcol + 8 * q) = h;
-                    *reinterpret_cast<uint2*>(sX + lrow * kLdH + 128 + lcol + 8 * q) = l;
-                }
-            }
-            MZ_TRACE_NW(6);                          // epilogue math
-            MZ_TRACE_NW(3);                          // epilogue
-            __syncthreads();
-            MZ_TRACE_NW(4);                          // barrier
-            if (gather) buf ^= 1;
-        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
-            float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
-            {
-                float rdot = 0.f;                  // reward head (games/tictactoe.py:193-195): this lane's 16 columns
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol + 8 * q);
-                    const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol + 8 * q);
-                    const float v[4] = {fmaxf(acc[4 * q] + bq.x, 0.f), fmaxf(acc[4 * q + 1] + bq.y, 0.f),
-                                        fmaxf(acc[4 * q + 2] + bq.z, 0.f), fmaxf(acc[4 * q + 3] + bq.w, 0.f)};
-                    rdot = __builtin_fmaf(v[0], rw.x, rdot);
-                    rdot = __builtin_fmaf(v[1], rw.y, rdot);
-                    rdot = __builtin_fmaf(v[2], rw.z, rdot);
-                    rdot = __builtin_fmaf(v[3], rw.w, rdot);
-                    uint2 h, l;
-                    split4(v, h, l);
-                    *reinterpret_cast<uint2*>(sH + lrow * kLdH + lcol + 8 * q) = h;
-                    *reinterpret_cast<uint2*>(sH + lrow * kLdH + 128 + lcol + 8 * q) = l;
-                    if (!SPLIT_IO && lrow_ok)                                                   // f32, unsplit
-                        *reinterpret_cast<float4*>(ocell + (unsigned)lrow * 1152u + lcol + 8 * q) =
-                            make_float4(v[0], v[1], v[2], v[3]);
-                }
-                rdot += __shfl_xor(rdot, 32);      // the row's other sixteen columns of this wave
-                if (lane < 32) sRew[wave * ROWS + lrow] = rdot;
-            }
-            MZ_TRACE_NW(3);
-            __syncthreads();
-            MZ_TRACE_NW(4);
-            if (SPLIT_IO) {          // sH is the row image the workspace wants: copied out 16 bytes a thread
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + kThreads * i, r = idx >> 5, c4 = idx & 31;
-                    if ((svalid >> i) & 1u)
-                        *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + c4 * 4) =
-                            *reinterpret_cast<const float4*>(sH + r * kLdH + c4 * 8);
-                }
-            }
-            if (tid < ROWS) {
-                int grow = row0 + tid;
-                asm volatile("" : "+v"(grow));      // address formed here, not hoisted out of the loop into a spilled pair
-                if ((rowmask >> tid) & 1u)
-                    rpart[(size_t)grow * 9 + cell] = (sRew[tid] + sRew[ROWS + tid]) + (sRew[2 * ROWS + tid] + sRew[3 * ROWS + tid]);
-            }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
-            if (!has_next) {      // end of the job: one partial per (game, job) instead of one per (game, cell)
-                int prow = row0;
-                asm volatile("" : "+s"(prow));      // addresses formed here, not sixteen pointers hoisted out of the loop
-                float* const pjob = ppart + (size_t)prow * 1152 + job * 128;
-                if (lrow_ok) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(pjob + (unsigned)lrow * 1152u + lcol + 8 * q) =
-                            make_float4(accp[4 * q], accp[4 * q + 1], accp[4 * q + 2], accp[4 * q + 3]);
-                }
-            }
-            MZ_TRACE_NW(6);                          // epilogue math
-            MZ_TRACE_NW(3);
-            __syncthreads();
-            MZ_TRACE_NW(4);
-            if (gather) buf ^= 1;
-        }
-        MZ_TRACE_NW(5);                              // after the barrier (reward dot)
-        Dc = Dn;
-        Dn = Dn2;
-        Dn2 = Dn3;
-    }
-}
-
-// ---- the job kernel on 64-row tiles
-// Same jobs, stages and outputs as ttt_job_kernel_h, for 64 games per 512-thread workgroup (one per CU).  The 32-row
-// kernel is bound by the bytes a CU pulls through its vector-memory path (64 KB of weight fragments per stage and 32
-// rows); here a workgroup still loads every fragment once, but for 64 rows: wave v owns output columns 16v .. 16v+15
+// ---- the TicTacToe job kernel
+// Recurrent inference, uniform-cost jobs.  A job = 64 games x a group of board cells chosen so that every workgroup runs
+// 16-18 GEMM stages: {centre, corner 0} = 11+6, {edges 1,3} = 8+8, {edges 5,7} = 8+8, {corners 2,6,8} = 6+6+6 (a cell
+// costs its valid conv taps + Dense + prediction-conv term).  4096 games -> 256 jobs, one 512-thread workgroup per CU.
+// Stage s multiplies with the weights requested during stage s-1 (in-place register ring) and the tile gathered during
+// stages s-2 / s-1.  A workgroup loads every weight fragment once for its 64 rows (a 32-row tile was bound by the bytes
+// a CU pulls through its vector-memory path): wave v owns output columns 16v .. 16v+15
 // of all 64 rows, as four 16-row blocks on v_mfma_f32_16x16x32_f16 (weights as the row operand, so a lane holds four
 // consecutive columns of one game per block).  A lane's operand for k-step s is the 8 halfs k = 32s + 8 (lane/16) .. +7
 // of column / game lane % 16: weights packed by Packer::add_split16, activations as [row][128 h | 128 l] images in LDS.
@@ -857,7 +253,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
     __shared__ __attribute__((aligned(16))) _Float16 sH[ROWS * kLdW];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
-    __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // as in ttt_job_kernel_h
+    __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // conv bias + action-plane bias of the current cell,
+                                                     // per action; [9*128..]: the cell's 128 reward-head weights;
+                                                     // [10*128..]: the dense layer's bias
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
     auto tile = [&](int b) { return sTileW[b]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -964,7 +362,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
         float bt[3];
         if (kind == 0 && first_tap) {
             // first tap of a cell: its bias table for all nine actions and its reward weights, requested ahead of this
-            // stage's weight loads and parked in LDS at the end of the stage (see ttt_job_kernel_h)
+            // stage's weight loads and parked in LDS at the end of the stage (a load issued in an epilogue would wait behind the next
+            // stage's weight loads: vmcnt is in-order)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int idx = tid + kThreadsW * i;
@@ -2084,18 +1483,6 @@ int ensure_scratch(mz_net* net, int batch) {
     return MZ_OK;
 }
 
-// MZ_JOB_F32=1: the f32-MFMA job kernel instead of the split-f16 one (comparison runs)
-bool job_f32() {
-    static const bool v = getenv("MZ_JOB_F32") != nullptr;
-    return v;
-}
-
-// MZ_JOB_ROWS32=1: the 32-row split-f16 job kernel instead of the 64-row one (comparison runs)
-bool job_rows32() {
-    static const bool v = getenv("MZ_JOB_ROWS32") != nullptr;
-    return v;
-}
-
 int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -2130,8 +1517,17 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
     net->kind = kind;
     net->stream = static_cast<hipStream_t>(stream);
     net->training_steps = training_steps;
+    // split-f16 domain (see "split-f16 MFMA" above): every weight must be finite and within f16's range
+    for (int64_t i = 0; i < num_weights; ++i) {
+        if (!(std::fabs(wh[i]) <= 65504.f)) {
+            delete net;
+            return mz::fail(MZ_ERR_INVALID_ARG, "weight %lld = %g is outside the kernels' operand range (finite, |w| <= 65504)",
+                            (long long)i, (double)wh[i]);
+        }
+    }
     Packer pk;
-    std::vector<size_t> off;
+    std::vector<std::pair<const float**, size_t>> fix;      // device pointer fields and their offsets in pk.buf
+    auto put = [&](const float*& field, size_t off) { fix.push_back({&field, off}); };
     const float* p = wh;
     auto take = [&](size_t n) {
         const float* q = p;
@@ -2139,6 +1535,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         return q;
     };
     if (kind == MZ_NET_TICTACTOE) {
+        TttDev& t = net->ttt;
         const float* rep_conv = take(3456);
         const float* rep_conv_b = take(128);
         const float* rep_dense = take(16384);
@@ -2157,45 +1554,26 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         const float* pred_value_b = take(1);
         const float* pred_policy = take(1152);         // (128,9)
         const float* pred_policy_b = take(9);
-        off.push_back(pk.add(rep_conv, 3456));                         // 0
-        off.push_back(pk.add(rep_conv_b, 128));                        // 1
-        off.push_back(pk.add_packed(rep_dense, 128, 128, 128));        // 2
-        off.push_back(pk.add(rep_dense_b, 128));                       // 3
-        size_t first = 0;
-        for (int t = 0; t < 9; ++t) {
-            const size_t o = pk.add_packed(dyn_conv + (size_t)t * 137 * 128, 128, 128, 128);
-            if (t == 0) first = o;
-        }
-        off.push_back(first);                                          // 4
+        put(t.rep_conv, pk.add(rep_conv, 3456));
+        put(t.rep_conv_b, pk.add(rep_conv_b, 128));
+        put(t.rep_dense_b, pk.add(rep_dense_b, 128));
         std::vector<float> actbias(9 * 9 * 128);
         for (int a = 0; a < 9; ++a)
             for (int c = 0; c < 9; ++c)
                 for (int n = 0; n < 128; ++n) {
                     double s = dyn_conv_b[n];
-                    for (int t = 0; t < 9; ++t) {
-                        const int ni = c / 3 + t / 3 - 1, nj = c % 3 + t % 3 - 1;
-                        if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) s += dyn_conv[((size_t)t * 137 + 128 + a) * 128 + n];
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
+                        if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) s += dyn_conv[((size_t)tp * 137 + 128 + a) * 128 + n];
                     }
                     actbias[((size_t)a * 9 + c) * 128 + n] = (float)s;
                 }
-        off.push_back(pk.add(actbias));                                // 5
-        off.push_back(pk.add_packed(dyn_dense, 128, 128, 128));        // 6
-        off.push_back(pk.add(dyn_dense_b, 128));                       // 7
-        off.push_back(pk.add(dyn_reward, 1152));                       // 8
-        for (int c = 0; c < 9; ++c) {
-            const size_t o = pk.add_packed(pred_conv + (size_t)c * 128 * 128, 128, 128, 128);
-            if (c == 0) first = o;
-        }
-        off.push_back(first);                                          // 9
-        off.push_back(pk.add(pred_conv_b, 128));                       // 10
-        off.push_back(pk.add_split16(pred_dense, 128, 128));           // 11
-        off.push_back(pk.add(pred_dense_b, 128));                      // 12
-        off.push_back(pk.add(pred_value, 128));                        // 13
-        std::vector<float> polT(9 * 128);
-        for (int k = 0; k < 128; ++k)
-            for (int o = 0; o < 9; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 9 + o];
-        off.push_back(pk.add(polT));                                   // 14
-        off.push_back(pk.add(pred_policy_b, 9));                       // 15
+        put(t.dyn_actbias, pk.add(actbias));
+        put(t.dyn_dense_b, pk.add(dyn_dense_b, 128));
+        put(t.dyn_reward_w, pk.add(dyn_reward, 1152));
+        put(t.pred_conv_b, pk.add(pred_conv_b, 128));
+        put(t.pred_dense_p, pk.add_split16(pred_dense, 128, 128));
+        put(t.pred_dense_b, pk.add(pred_dense_b, 128));
         std::vector<float> headW(128 * 16, 0.f), headB(16, 0.f);      // [k][16]: value | 9 policy | zeros
         for (int k = 0; k < 128; ++k) {
             headW[(size_t)k * 16] = pred_value[k];
@@ -2203,8 +1581,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         }
         headB[0] = pred_value_b[0];
         for (int o = 0; o < 9; ++o) headB[1 + o] = pred_policy_b[o];
-        net->ttt.dyn_reward_b = dyn_reward_b[0];
-        net->ttt.pred_value_b = pred_value_b[0];
+        t.dyn_reward_b = dyn_reward_b[0];
+        t.pred_value_b = pred_value_b[0];
         // stage descriptors of the four uniform-cost jobs: (kind | 8*first tap | 16*last tap, cell, tap, source cell)
         static const int kJobCells[4][3] = {{4, 0, -1}, {1, 3, -1}, {5, 7, -1}, {2, 6, 8}};
         std::vector<float> desc;      // int4 bit patterns stored in the float buffer
@@ -2217,52 +1595,41 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             }
         };
         for (int j = 0; j < 4; ++j) {
-            for (int ci = 0; ci < 3; ++ci) net->ttt.job_cells[j][ci] = kJobCells[j][ci];
-            net->ttt.job_first[j] = (int)desc.size() / 4;
+            for (int ci = 0; ci < 3; ++ci) t.job_cells[j][ci] = kJobCells[j][ci];
+            t.job_first[j] = (int)desc.size() / 4;
             for (int ci = 0; ci < 3; ++ci) {
                 const int c = kJobCells[j][ci];
                 if (c < 0) continue;
                 int valid[9], nv = 0;
-                for (int t = 0; t < 9; ++t) {
-                    const int ni = c / 3 + t / 3 - 1, nj = c % 3 + t % 3 - 1;
-                    if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) valid[nv++] = t;
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
+                    if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) valid[nv++] = tp;
                 }
                 for (int i = 0; i < nv; ++i) {
-                    const int t = valid[i];
-                    push(0 | (i == 0 ? 8 : 0) | (i == nv - 1 ? 16 : 0), c, t, (c / 3 + t / 3 - 1) * 3 + (c % 3 + t % 3 - 1));
+                    const int tp = valid[i];
+                    push(0 | (i == 0 ? 8 : 0) | (i == nv - 1 ? 16 : 0), c, tp, (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
                 }
                 push(1, c, 0, 0);
                 push(2, c, 0, 0);
             }
         }
-        net->ttt.job_first[4] = (int)desc.size() / 4;
-        off.push_back(pk.add(desc));                                   // 16
-        off.push_back(pk.add_split16(headW.data(), 16, 16));           // 17
-        off.push_back(pk.add(headB));                                  // 18
-        for (int t = 0; t < 9; ++t) {
-            const size_t o = pk.add_split_f16(dyn_conv + (size_t)t * 137 * 128, 128);
-            if (t == 0) first = o;
-        }
-        off.push_back(first);                                          // 19
-        off.push_back(pk.add_split_f16(dyn_dense, 128));               // 20
-        for (int c = 0; c < 9; ++c) {
-            const size_t o = pk.add_split_f16(pred_conv + (size_t)c * 128 * 128, 128);
-            if (c == 0) first = o;
-        }
-        off.push_back(first);                                          // 21
-        off.push_back(pk.add_split_f16(rep_dense, 128));               // 22
-        for (int t = 0; t < 9; ++t) {
-            const size_t o = pk.add_split16(dyn_conv + (size_t)t * 137 * 128, 128, 128);
-            if (t == 0) first = o;
-        }
-        off.push_back(first);                                          // 23
-        off.push_back(pk.add_split16(dyn_dense, 128, 128));               // 24
-        for (int c = 0; c < 9; ++c) {
-            const size_t o = pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128);
-            if (c == 0) first = o;
-        }
-        off.push_back(first);                                          // 25
+        t.job_first[4] = (int)desc.size() / 4;
+        put(reinterpret_cast<const float*&>(t.job_desc), pk.add(desc));
+        put(t.pred_head_p, pk.add_split16(headW.data(), 16, 16));
+        put(t.pred_head_b, pk.add(headB));
+        auto add_series = [&](const float*& field, int count, auto&& one) {      // `count` matrices, consecutive
+            for (int i = 0; i < count; ++i) {
+                const size_t o = one(i);
+                if (i == 0) put(field, o);
+            }
+        };
+        add_series(t.pred_conv_h, 9, [&](int c) { return pk.add_split_f16(pred_conv + (size_t)c * 128 * 128, 128); });
+        put(t.rep_dense_h, pk.add_split_f16(rep_dense, 128));
+        add_series(t.dyn_conv_s, 9, [&](int tp) { return pk.add_split16(dyn_conv + (size_t)tp * 137 * 128, 128, 128); });
+        put(t.dyn_dense_s, pk.add_split16(dyn_dense, 128, 128));
+        add_series(t.pred_conv_s, 9, [&](int c) { return pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128); });
     } else {
+        CartDev& c = net->cart;
         const float* rep_conv = take(51712);           // (4,101,128)
         const float* rep_conv_b = take(128);
         const float* rep_dense = take(16384);
@@ -2283,45 +1650,45 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         const float* pred_value_b = take(101);
         const float* pred_policy = take(256);          // (128,2)
         const float* pred_policy_b = take(2);
-        off.push_back(pk.add(rep_conv, 51712));                        // 0
-        off.push_back(pk.add(rep_conv_b, 128));                        // 1
-        off.push_back(pk.add_packed(rep_dense, 128, 128, 128));        // 2
-        off.push_back(pk.add(rep_dense_b, 128));                       // 3
-        off.push_back(pk.add_packed(dyn_conv, 128, 128, 128));         // 4
-        off.push_back(pk.add(dyn_conv_b, 128));                        // 5
+        put(c.rep_conv, pk.add(rep_conv, 51712));
+        put(c.rep_conv_b, pk.add(rep_conv_b, 128));
+        put(c.rep_dense_p, pk.add_packed(rep_dense, 128, 128, 128));
+        put(c.rep_dense_b, pk.add(rep_dense_b, 128));
+        put(c.dyn_conv_p, pk.add_packed(dyn_conv, 128, 128, 128));
+        put(c.dyn_conv_b, pk.add(dyn_conv_b, 128));
         std::vector<float> plane(128);
         for (int n = 0; n < 128; ++n) {
             double s = 0.0;
             for (int k = 0; k < 128; ++k) s += dyn_conv[((size_t)128 + k) * 128 + n];
             plane[n] = (float)s;
         }
-        off.push_back(pk.add(plane));                                  // 6
-        off.push_back(pk.add_packed(dyn_dense, 128, 128, 128));        // 7
-        off.push_back(pk.add(dyn_dense_b, 128));                       // 8
-        off.push_back(pk.add_packed(dyn_rdense, 128, 128, 128));       // 9
-        off.push_back(pk.add(dyn_rdense_b, 128));                      // 10
-        off.push_back(pk.add(dyn_reward, 128));                        // 11
-        off.push_back(pk.add_packed(pred_dense1, 128, 128, 128));      // 12
-        off.push_back(pk.add(pred_dense1_b, 128));                     // 13
-        off.push_back(pk.add_packed(pred_dense2, 128, 128, 128));      // 14
-        off.push_back(pk.add(pred_dense2_b, 128));                     // 15
-        off.push_back(pk.add_packed(pred_value, 128, 101, 101));       // 16
+        put(c.dyn_plane, pk.add(plane));
+        put(c.dyn_dense_p, pk.add_packed(dyn_dense, 128, 128, 128));
+        put(c.dyn_dense_b, pk.add(dyn_dense_b, 128));
+        put(c.dyn_rdense_p, pk.add_packed(dyn_rdense, 128, 128, 128));
+        put(c.dyn_rdense_b, pk.add(dyn_rdense_b, 128));
+        put(c.dyn_reward_w, pk.add(dyn_reward, 128));
+        put(c.pred_dense1_p, pk.add_packed(pred_dense1, 128, 128, 128));
+        put(c.pred_dense1_b, pk.add(pred_dense1_b, 128));
+        put(c.pred_dense2_p, pk.add_packed(pred_dense2, 128, 128, 128));
+        put(c.pred_dense2_b, pk.add(pred_dense2_b, 128));
+        put(c.pred_value_p, pk.add_packed(pred_value, 128, 101, 101));
         std::vector<float> vb(128, 0.f);
         for (int n = 0; n < 101; ++n) vb[n] = pred_value_b[n];
-        off.push_back(pk.add(vb));                                     // 17
+        put(c.pred_value_b, pk.add(vb));
         std::vector<float> polT(2 * 128);
         for (int k = 0; k < 128; ++k)
             for (int o = 0; o < 2; ++o) polT[(size_t)o * 128 + k] = pred_policy[(size_t)k * 2 + o];
-        off.push_back(pk.add(polT));                                   // 18
-        off.push_back(pk.add(pred_policy_b, 2));                       // 19
-        off.push_back(pk.add_split16(rep_dense, 128, 128));            // 20
-        off.push_back(pk.add_split16(dyn_conv, 128, 128));             // 21
-        off.push_back(pk.add_split16(dyn_dense, 128, 128));            // 22
-        off.push_back(pk.add_split16(dyn_rdense, 128, 128));           // 23
-        off.push_back(pk.add_split16(pred_dense1, 128, 128));          // 24
-        off.push_back(pk.add_split16(pred_dense2, 128, 128));          // 25
-        off.push_back(pk.add_split16(pred_value, 101, 101));           // 26
-        net->cart.dyn_reward_b = dyn_reward_b[0];
+        put(c.pred_policy_w, pk.add(polT));
+        put(c.pred_policy_b, pk.add(pred_policy_b, 2));
+        put(c.rep_dense_s, pk.add_split16(rep_dense, 128, 128));
+        put(c.dyn_conv_s, pk.add_split16(dyn_conv, 128, 128));
+        put(c.dyn_dense_s, pk.add_split16(dyn_dense, 128, 128));
+        put(c.dyn_rdense_s, pk.add_split16(dyn_rdense, 128, 128));
+        put(c.pred_dense1_s, pk.add_split16(pred_dense1, 128, 128));
+        put(c.pred_dense2_s, pk.add_split16(pred_dense2, 128, 128));
+        put(c.pred_value_s, pk.add_split16(pred_value, 101, 101));
+        c.dyn_reward_b = dyn_reward_b[0];
     }
     hipError_t e = hipGetDevice(&net->device);
     if (e == hipSuccess) {
@@ -2338,65 +1705,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         delete net;
         return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
-    const float* d = net->weights;
-    if (kind == MZ_NET_TICTACTOE) {
-        TttDev& t = net->ttt;
-        t.rep_conv = d + off[0];
-        t.rep_conv_b = d + off[1];
-        t.rep_dense_p = d + off[2];
-        t.rep_dense_b = d + off[3];
-        t.dyn_conv_p = d + off[4];
-        t.dyn_actbias = d + off[5];
-        t.dyn_dense_p = d + off[6];
-        t.dyn_dense_b = d + off[7];
-        t.dyn_reward_w = d + off[8];
-        t.pred_conv_p = d + off[9];
-        t.pred_conv_b = d + off[10];
-        t.pred_dense_p = d + off[11];
-        t.pred_dense_b = d + off[12];
-        t.pred_value_w = d + off[13];
-        t.pred_policy_w = d + off[14];
-        t.pred_policy_b = d + off[15];
-        t.job_desc = reinterpret_cast<const int4*>(d + off[16]);
-        t.pred_head_p = d + off[17];
-        t.pred_head_b = d + off[18];
-        t.dyn_conv_h = d + off[19];
-        t.dyn_dense_h = d + off[20];
-        t.pred_conv_h = d + off[21];
-        t.rep_dense_h = d + off[22];
-        t.dyn_conv_s = d + off[23];
-        t.dyn_dense_s = d + off[24];
-        t.pred_conv_s = d + off[25];
-    } else {
-        CartDev& c = net->cart;
-        c.rep_conv = d + off[0];
-        c.rep_conv_b = d + off[1];
-        c.rep_dense_p = d + off[2];
-        c.rep_dense_b = d + off[3];
-        c.dyn_conv_p = d + off[4];
-        c.dyn_conv_b = d + off[5];
-        c.dyn_plane = d + off[6];
-        c.dyn_dense_p = d + off[7];
-        c.dyn_dense_b = d + off[8];
-        c.dyn_rdense_p = d + off[9];
-        c.dyn_rdense_b = d + off[10];
-        c.dyn_reward_w = d + off[11];
-        c.pred_dense1_p = d + off[12];
-        c.pred_dense1_b = d + off[13];
-        c.pred_dense2_p = d + off[14];
-        c.pred_dense2_b = d + off[15];
-        c.pred_value_p = d + off[16];
-        c.pred_value_b = d + off[17];
-        c.pred_policy_w = d + off[18];
-        c.pred_policy_b = d + off[19];
-        c.rep_dense_s = d + off[20];
-        c.dyn_conv_s = d + off[21];
-        c.dyn_dense_s = d + off[22];
-        c.dyn_rdense_s = d + off[23];
-        c.pred_dense1_s = d + off[24];
-        c.pred_dense2_s = d + off[25];
-        c.pred_value_s = d + off[26];
-    }
+    for (auto& f : fix) *f.first = net->weights + f.second;
     *out_net = net;
     return MZ_OK;
 }
@@ -2414,6 +1723,12 @@ int mz_net_destroy(mz_net_t* net) {
 
 int mz_net_set_stream(mz_net_t* net, void* stream) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
+    if (net->stream != static_cast<hipStream_t>(stream)) {
+        // work enqueued on the old stream may still be using the handle's scratch, which a larger batch on the new
+        // stream would free and reallocate (ensure_scratch synchronises only the stream it runs on)
+        MZ_HIP(hipSetDevice(net->device));
+        MZ_HIP(hipStreamSynchronize(net->stream));
+    }
     net->stream = static_cast<hipStream_t>(stream);
     return MZ_OK;
 }
@@ -2439,17 +1754,9 @@ int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
     return MZ_OK;
 }
 
-// Rows per workgroup tile (32 or 64).  64 halves the weight traffic per game; 32 doubles the number of
-// workgroups, which wins while a 64-row grid cannot fill the 256 CUs.  MZ_TILE_ROWS overrides (experiments).
-static int tile_rows(const mz_net* net, int batch) {
-    static const int forced = [] {
-        const char* e = getenv("MZ_TILE_ROWS");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 32 || forced == 64) return forced;
-    const int wg64 = (batch + 63) / 64 * (net->kind == MZ_NET_TICTACTOE ? 9 : 1);
-    return wg64 >= 512 ? 64 : 32;
-}
+// Rows per workgroup tile (32 or 64) of the large-batch CartPole kernel.  64 halves the weight traffic per game; 32
+// doubles the number of workgroups, which wins while a 64-row grid cannot fill the 256 CUs.
+static int tile_rows(int batch) { return (batch + 63) / 64 >= 512 ? 64 : 32; }
 
 static int infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
                          float* out_logits, float* out_value_raw, bool split_hidden) {
@@ -2459,33 +1766,23 @@ static int infer_initial(mz_net_t* net, int32_t batch, const float* observation,
     if (batch == 0) return MZ_OK;
     MZ_REQUIRE(observation && out_hidden && out_value && out_logits, "observation/out_hidden/out_value/out_logits is NULL");
     MZ_HIP(hipSetDevice(net->device));
-    const int rows = tile_rows(net, batch);
+    const int rows = tile_rows(batch);
     const int nrb = (batch + rows - 1) / rows;
     hipStream_t st = net->stream;
     if (net->kind == MZ_NET_TICTACTOE) {
         int s = ensure_scratch(net, batch);
         if (s != MZ_OK) return s;
         const int nhb = (batch + 15) / 16;
-        if (job_f32()) {
-            if (rows == 64)
-                ttt_cell_kernel<2><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, out_hidden, net->ppart);
-            else
-                ttt_cell_kernel<1><<<9 * nrb, kThreads, 0, st>>>(net->ttt, batch, observation, out_hidden, net->ppart);
-            if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-            ttt_head_kernel<true, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                              out_value, out_logits, out_value_raw);
-        } else {
-            const int nrb32 = (batch + 31) / 32;
-            if (split_hidden)
-                ttt_initial_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
-                                                                                       out_hidden, net->ppart);
-            else
-                ttt_initial_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
-                                                                                        out_hidden, net->ppart);
-            if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-            ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                              out_value, out_logits, out_value_raw);
-        }
+        const int nrb32 = (batch + 31) / 32;
+        if (split_hidden)
+            ttt_initial_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
+                                                                                   out_hidden, net->ppart);
+        else
+            ttt_initial_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
+                                                                                    out_hidden, net->ppart);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
+        ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                          out_value, out_logits, out_value_raw);
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<true><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
                                                                          out_hidden, nullptr, out_value, out_logits,
@@ -2506,28 +1803,17 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
     return infer_initial(net, batch, observation, out_hidden, out_value, out_logits, out_value_raw, false);
 }
 
-// The split-f16 TicTacToe job kernel of this build (64-row tiles, or 32-row ones under MZ_JOB_ROWS32), reading and writing
-// f32 hidden rows or, inside a native move, their split images.
+// The TicTacToe job kernel, reading and writing f32 hidden rows or, inside a native move, their split images.
 static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, const int* parent_block, long bs,
                               const int* action, float* out_hidden, bool split_hidden, float* ppart, float* rpart) {
     hipStream_t st = net->stream;
-    if (job_rows32()) {
-        const int grid = 32 * (((batch + 31) / 32 + 7) / 8);
-        if (split_hidden)
-            ttt_job_kernel_h<true><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                              out_hidden, ppart, rpart);
-        else
-            ttt_job_kernel_h<false><<<grid, kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                               out_hidden, ppart, rpart);
-    } else {
-        const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
-        if (split_hidden)
-            ttt_job_kernel_w<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                               out_hidden, ppart, rpart);
-        else
-            ttt_job_kernel_w<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                                out_hidden, ppart, rpart);
-    }
+    const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
+    if (split_hidden)
+        ttt_job_kernel_w<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                           out_hidden, ppart, rpart);
+    else
+        ttt_job_kernel_w<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                            out_hidden, ppart, rpart);
 }
 
 // split_hidden: the hidden rows read and written are the split images of a native move's workspace (TicTacToe)
@@ -2543,7 +1829,7 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
                "hidden_base/action/out_hidden/out_reward/out_value/out_logits is NULL");
     MZ_REQUIRE(block_stride >= 0, "block_stride must be >= 0");
     MZ_HIP(hipSetDevice(net->device));
-    const int rows = tile_rows(net, batch);
+    const int rows = tile_rows(batch);
     const int nrb = (batch + rows - 1) / rows;
     hipStream_t st = net->stream;
     const long bs = (long)block_stride;
@@ -2554,12 +1840,7 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
             ppart = net->ppart;
             rpart = net->rpart;
         }
-        const int nrb32 = (batch + 31) / 32;
-        if (job_f32())
-            ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs,
-                                                                        action, out_hidden, ppart, rpart);
-        else
-            launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden, ppart, rpart);
+        launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden, ppart, rpart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
         ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
@@ -2612,12 +1893,17 @@ int mz_infer_recurrent_noalloc(mz_net_t* net, int32_t batch, const float* hidden
 // workspace, so the TicTacToe kernels keep it as split images from the root rows on (until mz_net_end_move).
 __attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, int batch, const float* observation,
                                                             float* hidden_block0, float* out_value, float* out_logits) {
-    const bool split = net != nullptr && net->kind == MZ_NET_TICTACTOE && !job_f32();
+    const bool split = net != nullptr && net->kind == MZ_NET_TICTACTOE;
     const int s = infer_initial(net, batch, observation, hidden_block0, out_value, out_logits, nullptr, split);
     if (s == MZ_OK && batch > 0) net->hidden_split = split;
     return s;
 }
 __attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->hidden_split = false; }
+__attribute__((visibility("hidden"))) int mz_net_hidden_size_of(const mz_net* net) { return mz_net_hidden_size(net->kind); }
+__attribute__((visibility("hidden"))) int mz_net_num_actions_of(const mz_net* net) {
+    return net->kind == MZ_NET_TICTACTOE ? 9 : net->kind == MZ_NET_CARTPOLE ? 2 : -1;
+}
+__attribute__((visibility("hidden"))) hipStream_t mz_net_stream_of(const mz_net* net) { return net->stream; }
 
 int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,
                             int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,
@@ -2628,10 +1914,9 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     MZ_REQUIRE(block_stride >= 0, "block_stride must be >= 0");
     MZ_REQUIRE(net->device == pool->device && net->stream == pool->stream, "net and pool must share device and stream");
     const int batch = pool->dev.T;
-    static const bool no_fusion = getenv("MZ_NO_FUSED_STEP") != nullptr;          // experiments
-    const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9 && !no_fusion;
-    const bool fusable_cart = net->kind == MZ_NET_CARTPOLE && pool->G == 2 && pool->dev.A == 2 &&
-                              batch <= kCart16MaxBatch && !no_fusion;
+    // the fused launches are built for the default lane counts; other pools run the same work as separate launches
+    const bool fusable = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->dev.A == 9;
+    const bool fusable_cart = net->kind == MZ_NET_CARTPOLE && pool->G == 2 && pool->dev.A == 2 && batch <= kCart16MaxBatch;
     if (fusable_cart) {                               // CartPole: network and tree step of 16 games in one workgroup
         int nb = 0;
         int s = mz_pool_begin_backprop(pool, with_select != 0, &nb);
@@ -2667,14 +1952,8 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     s = ensure_scratch(net, batch);
     if (s != MZ_OK) return s;
     hipStream_t st = net->stream;
-    const int nrb32 = (batch + 31) / 32;
-    if (job_f32())
-        ttt_job_kernel<<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, hidden_base, parent_block,
-                                                                    (long)block_stride, action, out_hidden, net->ppart,
-                                                                    net->rpart);
-    else
-        launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
-                          net->ppart, net->rpart);
+    launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
+                      net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
     const int grid = (batch + 15) / 16;
     if (with_select)

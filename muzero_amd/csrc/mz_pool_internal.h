@@ -15,6 +15,8 @@ struct mz_pool {
     size_t bytes = 0;
     std::vector<void*> allocations;
     long long* counter_scratch = nullptr;
+    double* pow_dev = nullptr;  // PoolDev::pow_table
+    int pow_next = 0;           // next temperature table to replace once all kPowTables are taken
 };
 
 // Call-sequence bookkeeping of one expand+backprop (fused with the next select when `with_select`): checks what
@@ -29,6 +31,11 @@ struct mz_net;
 extern "C" int mz_net_begin_move(mz_net* net, int batch, const float* observation, float* hidden_block0, float* out_value,
                                  float* out_logits);
 extern "C" void mz_net_end_move(mz_net* net);
+
+// what mz_search_move checks a network handle against (mz_net.hip)
+extern "C" int mz_net_hidden_size_of(const mz_net* net);
+extern "C" int mz_net_num_actions_of(const mz_net* net);
+extern "C" hipStream_t mz_net_stream_of(const mz_net* net);
 
 // mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL), one launch
 extern "C" int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits, const int32_t* legal,

@@ -1,7 +1,7 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as 2N+5 HIP launches (TicTacToe) on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as 2N+5 HIP launches (TicTacToe; N+4 for CartPole) on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
@@ -12,6 +12,17 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
     MZ_REQUIRE(io->hidden && io->logits && io->reward && io->value && io->parent_block && io->action,
                "hidden/logits/reward/value/parent_block/action workspaces must be non-NULL");
     MZ_REQUIRE(io->num_trees >= 1 && io->num_simulations >= 1 && io->hidden_size >= 1, "bad sizes in mz_move_io_t");
+    // every launch below sizes its grid by the pool and addresses the workspaces by io: they must describe the same move
+    MZ_REQUIRE(io->num_trees == pool->dev.T, "mz_move_io_t.num_trees = %d, the pool holds %d trees", io->num_trees,
+               pool->dev.T);
+    MZ_REQUIRE(io->num_simulations <= pool->dev.N, "mz_move_io_t.num_simulations = %d exceeds the pool's max_simulations %d",
+               io->num_simulations, pool->dev.N);
+    MZ_REQUIRE(io->hidden_size == mz_net_hidden_size_of(net), "mz_move_io_t.hidden_size = %d, the network's hidden state has %d floats",
+               io->hidden_size, mz_net_hidden_size_of(net));
+    MZ_REQUIRE(mz_net_num_actions_of(net) == pool->dev.A, "the network has %d actions, the pool %d", mz_net_num_actions_of(net),
+               pool->dev.A);
+    MZ_REQUIRE(static_cast<hipStream_t>(io->stream) == pool->stream, "mz_move_io_t.stream is not the pool's stream");
+    MZ_REQUIRE(mz_net_stream_of(net) == pool->stream, "net and pool must launch on the same stream");
     const int T = io->num_trees, N = io->num_simulations;
     const int64_t H = io->hidden_size;
     void** ev = io->events;

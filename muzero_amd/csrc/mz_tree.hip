@@ -11,22 +11,23 @@
 //   select_action/softmax      agent.py:162-168,213-217
 //
 // Layout.  Tree t owns N+1 records ("blocks") of RS bytes (a multiple of 128), block e at blocks + (t*(N+1)+e)*RS:
-//     select half:  q f64[A] | visit_count i32[A] | prior f32[A] | child i32[A]          (20*A bytes, SoA)
-//     backup half:  { value_sum f64, reward f32, pad } [A]                               (16*A bytes, AoS)
-// One dependent step of a descent reads the contiguous select half with every field coalesced over the lanes of a
-// group; a backup touches ONE 16-byte backup entry per path node (its visit count travels in the path entry) and
-// writes count and q of that slot.  q = reward + discount*value_sum/visit_count, the exploitation term of ucb_score
-// (agent.py:188), already normalised when the value bounds are known: computed once per backup with the same IEEE
-// operations the reference performs at every look, so select divides only for visited children.
-// Block e is the node expanded by simulation e-1 in every tree (lockstep), block 0 is the root.  Only visit_count
-// and prior are initialised at expansion; q/child/value_sum/reward of a slot are written by the first backup
-// through it (visited <=> expanded) and never read before.
+//     select half:  Slot[A]     { q f64, visit_count i32, prior f32, child_hi i32, act i32 }   24 B, array of structures
+//     backup half:  BackSlot[A] { value_sum f64, reward f32, pad }                             16 B, array of structures
+// (mz_tree_dev.h).  One dependent step of a descent reads whole slots, one per lane; a backup touches ONE 16-byte backup
+// entry per path node (its visit count travels in the path entry) and writes count and q of that slot.
+// q = reward + discount*value_sum/visit_count, the exploitation term of ucb_score (agent.py:188), already normalised when
+// the value bounds are known: computed once per backup with the same IEEE operations the reference performs at every
+// look, so select divides only for visited children.
+// Block e is the node expanded by simulation e-1 in every tree (lockstep), block 0 is the root.  Only visit_count, prior
+// and act are initialised at expansion; q / child_hi / value_sum / reward of a slot are written by the first backup
+// through it (visited <=> expanded) and never read before.  Below the root a node keeps its children by descending prior
+// (slot 0 = action 0), so that select scores a prefix of the node (select_tree, mz_tree_dev.h).
 // Root priors are fp64 after the noise mix (agent.py:175) and live in root_prior[T][A]; the root's action list is
 // the act field of its slots.
 //
-// Execution.  One group of G lanes per tree, G = the power of two >= A (2..64): 64/G trees per wavefront,
-// lanes stride over the children, (score, action) arg-max by __shfl_xor inside the group.  Every tree keeps
-// the same group -> workgroup -> XCD assignment in every launch, so its records stay in that XCD's L2.
+// Execution.  One group of G lanes per tree (2..64, group_width below): 64/G trees per wavefront, lanes stride over the
+// slots, (score, action) arg-max by DPP / permlane-swap steps inside the group (no LDS).  Every tree keeps the same
+// group -> workgroup -> XCD assignment in every launch, so its records stay in that XCD's L2.
 //
 // Numerics (SURVEY.md traps T1-T8): fp64 scores, fp32 priors/rewards widened, no FMA contraction
 // (compiled with -ffp-contract=off), 2*log(n+1) tabulated by the host libm, ties to the largest action,
@@ -261,14 +262,21 @@ __device__ __forceinline__ void select_action_tree(const PoolDev& p, int tree, i
         return;
     }
     const double inv_t = 1 / t;
+    // count ** (1/t) is the host libm's pow in the reference (agent.py:167), which no device pow reproduces bit for bit:
+    // a temperature registered with mz_pool_set_temperature_table is looked up in the host's own table
+    const double* tab = nullptr;
+#pragma unroll
+    for (int i = 0; i < kPowTables; ++i)
+        if (i < p.n_pow && p.pow_t[i] == t) tab = p.pow_table + (size_t)i * (p.N + 1);
     auto weight = [&](int c) -> double {
+        if (tab != nullptr) return tab[min(max(c, 0), p.N)];
         if (inv_t == 1.0) return (double)c;       // pow(c, 1.0) == c exactly
         if (inv_t == 2.0) return (double)c * (double)c;
         if (inv_t == 4.0) {
             const double c2 = (double)c * (double)c;
             return c2 * c2;
         }
-        return pow((double)c, inv_t);
+        return pow((double)c, inv_t);             // unregistered temperature: the device's pow (not bit-exact)
     };
     for (int k = lane; k < n; k += 64) {
         s_w[k] = weight(slots[k].count);
@@ -558,17 +566,19 @@ int mz_pool_create(const mz_pool_config_t* cfg, void* stream, mz_pool_t** out_po
         if ((status = dev_alloc(pool, &d.err_flag, (size_t)1)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &log_dev, (size_t)d.N + 2)) != MZ_OK) break;
         if ((status = dev_alloc(pool, &pool->counter_scratch, (size_t)2)) != MZ_OK) break;
+        if ((status = dev_alloc(pool, &pool->pow_dev, (size_t)kPowTables * (d.N + 1))) != MZ_OK) break;
+        d.pow_table = pool->pow_dev;
+        d.n_pow = 0;
         std::vector<double> table(d.N + 2);
         for (int n = 0; n < d.N + 2; ++n)
             table[n] = cfg->log_table ? cfg->log_table[n] : 2 * std::log((double)(n + 1));   // config.py:160
         // Children kept by descending prior, so that select reads a prefix of a node (mz_tree_dev.h, select_tree): sound
         // when the exploration factor is finite and >= 0 (it is 2 log(n+1) unless the caller's table says otherwise) and
-        // worth it when ranking a new node's children is cheap.  MZ_TREE_NO_SORT=1 switches it off (profiling aid).
+        // worth it when ranking a new node's children is cheap.
         bool table_ok = true;
         for (double x : table) table_ok = table_ok && x >= 0.0 && std::isfinite(x);
         const int per_lane = (d.A + pool->G - 1) / pool->G;
-        const char* no_sort = std::getenv("MZ_TREE_NO_SORT");
-        d.sort_nodes = (table_ok && d.A >= 4 && d.A * per_lane <= 512 && !(no_sort && no_sort[0] == '1')) ? 1 : 0;
+        d.sort_nodes = (table_ok && d.A >= 4 && d.A * per_lane <= 512) ? 1 : 0;
         std::vector<int> leaves, merges;
         build_sum_program(0, d.A, leaves, merges);
         d.n_sum_leaf = (int)leaves.size() / 2;
@@ -618,6 +628,26 @@ int mz_pool_destroy(mz_pool_t* pool) {
 int mz_pool_set_stream(mz_pool_t* pool, void* stream) {
     MZ_REQUIRE(pool != nullptr, "pool is NULL");
     pool->stream = static_cast<hipStream_t>(stream);
+    return MZ_OK;
+}
+
+int mz_pool_set_temperature_table(mz_pool_t* pool, double temperature, const double* weights_host) {
+    MZ_REQUIRE(pool != nullptr && weights_host != nullptr, "pool/weights_host is NULL");
+    MZ_REQUIRE(temperature == temperature && temperature != 0.0, "temperature must be a non-zero number (0 is the arg-max)");
+    PoolDev& d = pool->dev;
+    int slot = -1;
+    for (int i = 0; i < d.n_pow; ++i)
+        if (d.pow_t[i] == temperature) slot = i;
+    if (slot < 0) {
+        slot = d.n_pow < kPowTables ? d.n_pow : pool->pow_next;      // full: replace the oldest registration
+        if (d.n_pow == kPowTables) pool->pow_next = (pool->pow_next + 1) % kPowTables;
+    }
+    MZ_HIP(hipSetDevice(pool->device));
+    MZ_HIP(hipStreamSynchronize(pool->stream));      // launches in flight may still read the slot being replaced
+    MZ_HIP(hipMemcpy(pool->pow_dev + (size_t)slot * (d.N + 1), weights_host, (size_t)(d.N + 1) * sizeof(double),
+                     hipMemcpyHostToDevice));
+    d.pow_t[slot] = temperature;
+    if (slot == d.n_pow) d.n_pow++;
     return MZ_OK;
 }
 
@@ -780,6 +810,23 @@ int mz_pool_read_block(mz_pool_t* pool, int32_t tree, int32_t block, int32_t* ou
         if (reward) reward[k] = visited ? back[s].reward : std::numeric_limits<float>::quiet_NaN();
         if (child) child[k] = visited ? (slots[s].child_hi & kChildMask) : -1;
     }
+    return MZ_OK;
+}
+
+int mz_pool_read_root_priors(mz_pool_t* pool, int32_t tree, int32_t* out_num_children, float* priors) {
+    MZ_REQUIRE(pool != nullptr && priors != nullptr, "pool/priors is NULL");
+    const PoolDev& d = pool->dev;
+    MZ_REQUIRE(tree >= 0 && tree < d.T, "tree %d out of range [0,%d)", tree, d.T);
+    MZ_REQUIRE(pool->blocks_in_use >= 1, "roots are not expanded");
+    MZ_HIP(hipSetDevice(pool->device));
+    MZ_HIP(hipStreamSynchronize(pool->stream));
+    int n = 0;
+    MZ_HIP(hipMemcpy(&n, d.n_root + tree, sizeof(int), hipMemcpyDeviceToHost));
+    if (out_num_children) *out_num_children = n;
+    std::vector<char> recbuf(d.RS);
+    MZ_HIP(hipMemcpy(recbuf.data(), d.blocks + (size_t)tree * d.tree_stride, d.RS, hipMemcpyDeviceToHost));
+    const Slot* slots = reinterpret_cast<const Slot*>(recbuf.data());
+    for (int k = 0; k < n; ++k) priors[k] = slots[k].prior;
     return MZ_OK;
 }
 

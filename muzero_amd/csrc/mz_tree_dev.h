@@ -35,6 +35,8 @@ struct __attribute__((aligned(16))) BackSlot {
     int pad;
 };
 
+constexpr int kPowTables = 8;                  // temperature tables a pool holds (mz_pool_set_temperature_table)
+
 struct PoolDev {
     int T, A, N;
     int has_bounds;
@@ -60,6 +62,9 @@ struct PoolDev {
     const int* sum_merge;      // ... and merges (dst, src)
     int n_sum_leaf, n_sum_merge;
     double discount, default_value, kmin, kmax;
+    int n_pow;                 // registered temperature tables
+    double pow_t[kPowTables];  // their temperatures ...
+    const double* pow_table;   // ... and weights: [kPowTables][N+1], entry c = float(c) ** (1/t) by the host's libm
 };
 
 __device__ __forceinline__ char* rec(const PoolDev& p, int tree, int e) {

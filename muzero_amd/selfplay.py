@@ -315,7 +315,10 @@ class SelfPlayEngine:
             hist.to_plays[m].copy_(env.to_play)
             noise = self._dirichlet(n_legal)
             u = torch.rand(self.G, dtype=torch.float64, device=self.device, generator=self.generator)
-            self.temperature.fill_(float(cfg.visit_softmax_temperature_fn(num_moves=m, training_steps=steps)))
+            t = float(cfg.visit_softmax_temperature_fn(num_moves=m, training_steps=steps))
+            self.temperature.fill_(t)
+            for lane in getattr(self.search, 'lanes', [self.search]):
+                lane.pool.set_temperature(t)         # exact count ** (1/t) sampling weights (agent.py:167)
             _visits, root_value, _minmax, policy, action = self.search.run(obs, noise, u, self.temperature, legal,
                                                                            n_legal)
             hist.actions[m].copy_(action)

@@ -49,6 +49,7 @@ class TreePool:
             self._stream = torch.cuda.current_stream(self.device).cuda_stream
             _lib.check(self._lib.mz_pool_create(ctypes.byref(cfg), ctypes.c_void_p(self._stream), ctypes.byref(handle)))
         self._h = handle
+        self._last_temperature = None
         i32 = dict(dtype=torch.int32, device=self.device)
         self._parent = torch.empty(self.T, **i32)
         self._action = torch.empty(self.T, **i32)
@@ -156,11 +157,27 @@ class TreePool:
                                            policy.data_ptr()))
         return visits, root_value, minmax, policy
 
+    def set_temperature(self, temperature):
+        """Registers the exact sampling weights count ** (1/t), c = 0..N, evaluated HERE by CPython like the reference
+        does (agent.py:167: int ** float = the host libm's pow), for a temperature about to be used
+        (mz_pool_set_temperature_table).  Cheap to call again with the temperature of the previous call."""
+        t = float(temperature)
+        if t == self._last_temperature:
+            return
+        self._last_temperature = t
+        if t == 0.0 or 1 / t in (1.0, 2.0, 4.0):          # arg-max / exact products on the device: no table needed
+            return
+        self._sync_stream()
+        table = np.array([c ** (1 / t) for c in range(self.N + 1)], np.float64)
+        _lib.check(self._lib.mz_pool_set_temperature_table(self._h, t, table.ctypes.data))
+
     def select_action(self, u, temperature):
-        """softmax_sample (agent.py:162-168) with injected uniforms u [T] f64, temperature [T] f64."""
+        """softmax_sample (agent.py:162-168) with injected uniforms u [T] f64 and temperature: a number, or [T] f64
+        (then register every distinct value with set_temperature first)."""
         self._sync_stream()
         up = _check_tensor('u', u, torch.float64, (self.T,), self.device)
         if not isinstance(temperature, torch.Tensor):
+            self.set_temperature(temperature)
             temperature = torch.full((self.T,), float(temperature), dtype=torch.float64, device=self.device)
         tp = _check_tensor('temperature', temperature, torch.float64, (self.T,), self.device)
         out = torch.empty(self.T, dtype=torch.int32, device=self.device)
@@ -173,6 +190,14 @@ class TreePool:
         out = np.zeros(4, np.int64)
         _lib.check(self._lib.mz_pool_counters(self._h, out.ctypes.data))
         return out
+
+    def read_root_priors(self, tree):
+        """The root's float32 priors before the noise mix, one per listed child (host copy; synchronises)."""
+        self._sync_stream()
+        n = ctypes.c_int32(0)
+        out = np.zeros(self.A, np.float32)
+        _lib.check(self._lib.mz_pool_read_root_priors(self._h, int(tree), ctypes.addressof(n), out.ctypes.data))
+        return out[:n.value]
 
     def read_block(self, tree, block):
         """Host copy of one block (Node views, tests); synchronises."""

@@ -245,7 +245,7 @@ def dump_tree(root, A, N):
     return out
 
 
-def run_case(name, A, N, num_players, discount, default_value, known_bounds, legal, seed,
+def _run_case(name, A, N, num_players, discount, default_value, known_bounds, legal, seed,
              temperature=1.0, num_moves=0, freezing_moves=10, frac=0.25, alpha=1.0,
              value_mode='tanh', reward_mode='uniform', logit_scale=1.0, full_tree=True):
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -282,8 +282,15 @@ def run_case(name, A, N, num_players, discount, default_value, known_bounds, leg
         drawn['noise'] = np.array(noise, np.float64)
         return noise
 
+    real_choices = random.choices
+
+    def recording_choices(population, weights=None, **kw):      # softmax_sample's weights, as the reference computed them
+        drawn['choice_weights'] = np.array(weights, np.float64)
+        return real_choices(population, weights=weights, **kw)
+
     np.random.seed(seed)
     np.random.dirichlet = recording_dirichlet
+    random.choices = recording_choices
     EraNetworkOutput.recorded_priors = []
     try:
         # -- the body of MCTSAgent.make_move (agent.py:219-232), step by step so the root stays inspectable
@@ -307,6 +314,7 @@ def run_case(name, A, N, num_players, discount, default_value, known_bounds, leg
         action = mcts.select_action(root, len(game.history))
     finally:
         np.random.dirichlet = real_dirichlet
+        random.choices = real_choices
         priors = EraNetworkOutput.recorded_priors
         EraNetworkOutput.recorded_priors = None
 
@@ -330,6 +338,8 @@ def run_case(name, A, N, num_players, discount, default_value, known_bounds, leg
         root_visits=visits, root_count=np.int32(root.visit_count), root_vsum=np.float64(root.value_sum),
         root_value=np.float64(root.value), mm_min=np.float64(mm.minimum), mm_max=np.float64(mm.maximum),
         policy=policy32, action=np.int32(action))
+    if 'choice_weights' in drawn:         # count ** (1 / t) per root child in insertion order (agent.py:167)
+        out['choice_weights'] = drawn['choice_weights']
     if A <= 32:
         out['logits'] = logits
     if full_tree:
@@ -350,7 +360,7 @@ def max_depth(node):
     return best
 
 
-def tictactoe_game(name, seed, N):
+def _tictactoe_game(name, seed, N):
     """A full reference self-play game (agent.py:31-44) on the reference TicTacToeEnvironment."""
     import games.tictactoe as ttt
     config = ttt.make_config.__globals__['MuZeroConfig'](
@@ -417,6 +427,16 @@ def tictactoe_game(name, seed, N):
 
 
 def main():
+    only = set(sys.argv[1:])              # optional: generate only the named fixtures
+
+    def run_case(name, **kw):
+        if not only or name in only:
+            _run_case(name, **kw)
+
+    def tictactoe_game(name, **kw):
+        if not only or name in only:
+            _tictactoe_game(name, **kw)
+
     # TicTacToe-shaped (C1/C3): 2 players, known bounds (-1,1) via KnownBounds(None, 1.0), discount 1 -> -1
     run_case('ttt_full_s1', A=9, N=25, num_players=2, discount=1.0, default_value=0.0, known_bounds=(None, 1.0),
              legal=list(range(9)), seed=1, reward_mode='tanh')
@@ -453,6 +473,11 @@ def main():
     # symmetric bounds given explicitly, discount<1, asymmetric range
     run_case('asym_bounds_s15', A=6, N=64, num_players=1, discount=0.5, default_value=-1.0, known_bounds=(-2.0, 3.0),
              legal=[5, 0, 3], seed=15, reward_mode='tanh')   # non-monotone legal list: insertion order != action order
+    # temperatures whose 1/t is not a small integer: count ** (1/t) goes through the host libm's pow (agent.py:167)
+    run_case('temp07_s16', A=9, N=25, num_players=2, discount=1.0, default_value=0.0, known_bounds=(None, 1.0),
+             legal=[0, 1, 2, 4, 5, 7, 8], seed=16, reward_mode='tanh', temperature=0.7)
+    run_case('temp3_s17', A=18, N=50, num_players=1, discount=0.997, default_value=0.0, known_bounds=None,
+             legal=list(range(18)), seed=17, temperature=3.0)
     tictactoe_game('ttt_game_s21', seed=21, N=25)
     tictactoe_game('ttt_game_s22', seed=22, N=20)
 

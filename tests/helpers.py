@@ -63,6 +63,8 @@ def run_fixture_on_pool(pool, fx, ad, fused=False):
             pool.expand_backprop(*args)
             parent, action = pool.select()
     visits, root_value, minmax, policy = (ad.get(x) for x in pool.root_stats())
+    if hasattr(pool, 'set_temperature'):      # HIP pool: the host tabulates count ** (1/t) (mz_pool_set_temperature_table)
+        pool.set_temperature(fixture_temperature(fx))
     chosen = ad.get(pool.select_action(ad.put(np.full(T, float(fx['u']), np.float64)),
                                        ad.put(np.full(T, fixture_temperature(fx), np.float64))))
     return dict(trace_parent=np.stack(trace_parent, 1), trace_action=np.stack(trace_action, 1), visits=visits,
@@ -161,6 +163,8 @@ def run_synthetic_on_pool(pool, inp, ad, frac=0.25, fused=False, temperature=1.0
             pool.expand_backprop(*args, **kw)
             parent, action = pool.select()
     visits, root_value, minmax, policy = (ad.get(x) for x in pool.root_stats())
+    if hasattr(pool, 'set_temperature'):
+        pool.set_temperature(temperature)
     chosen = ad.get(pool.select_action(ad.put(inp['u']), ad.put(np.full(T, temperature, np.float64))))
     return dict(trace_parent=np.stack(trace_parent, 1), trace_action=np.stack(trace_action, 1), visits=visits,
                 root_value=root_value, minmax=minmax, policy=policy, action=chosen, counters=pool.counters())
@@ -172,3 +176,15 @@ def assert_same_search(a, b):
     np.testing.assert_array_equal(a['root_value'], b['root_value'])      # NaN == NaN positions included
     np.testing.assert_array_equal(a['minmax'], b['minmax'])
     np.testing.assert_array_equal(a['counters'][:2], b['counters'][:2])
+
+
+def reference_sample(fx, u):
+    """softmax_sample (agent.py:162-168) over the fixture's root with the weights the REFERENCE computed
+    (fx['choice_weights'] = count ** (1/t) per child in insertion order, recorded from its random.choices call):
+    CPython's random.choices = population[bisect_right(accumulate(weights), u * total, 0, n - 1)]."""
+    import bisect
+    import itertools
+    w = [float(x) for x in fx['choice_weights']]
+    cum = list(itertools.accumulate(w))
+    total = cum[-1] + 0.0
+    return int(fx['legal'][bisect.bisect_right(cum, u * total, 0, len(w) - 1)])

@@ -49,6 +49,30 @@ def test_c_oracle_matches_reference(name):
     assert_blocks_match_fixture(pool, fx, tree=2)
 
 
+SAMPLED_FIXTURES = [n for n in TREE_FIXTURES if 'choice_weights' in load_golden(n)]
+
+
+@pytest.mark.parametrize('name', SAMPLED_FIXTURES)
+def test_oracles_sample_with_the_reference_weights(name):
+    """count ** (1/t) for temperatures whose 1/t is no small integer (agent.py:167): both oracles reproduce the weights the
+    reference passed to random.choices, and the action it would draw for any uniform."""
+    from helpers import fixture_temperature, reference_sample
+    fx = load_golden(name)
+    t = fixture_temperature(fx)
+    tree, _, _, _ = mcts_oracle.run_fixture(fx)
+    counts = [int(fx['root_visits'][a]) for a in fx['legal']]
+    np.testing.assert_array_equal(np.array([c ** (1 / t) for c in counts]), fx['choice_weights'])
+    us = np.concatenate([np.linspace(0.0, 1.0, 300, endpoint=False), [float(fx['u']), np.nextafter(1.0, 0.0)]])
+    T = len(us)
+    pool = c_oracle.OraclePool(**fixture_kwargs(fx, num_trees=T))
+    run_fixture_on_pool(pool, fx, NumpyAdapter)
+    got = pool.select_action(us, t)
+    for i, u in enumerate(us):
+        want = reference_sample(fx, float(u))
+        assert tree.select_action(float(u), t) == want
+        assert got[i] == want, (i, u)
+
+
 def test_numpy_pairwise_sum_model():
     """Trap T4: the oracle's fp32 summation equals ndarray.sum bit for bit, sizes 1..700."""
     rng = np.random.Generator(np.random.PCG64(7))

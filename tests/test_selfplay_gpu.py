@@ -88,29 +88,83 @@ def test_lockstep_search_with_network_in_the_loop(game):
         for e in range(N + 1):
             p = search.pool.read_block(int(t), e)['prior']
             priors[e, t, :len(p)] = p if e else 0
-    # root priors were noise-mixed on the device; rebuild the pre-noise fp32 priors from the logits path instead
+    # the root's fp32 priors as the device derived them from the logits, before the noise mix (its expf is <= 2 ulp from
+    # NumPy's exp, trap T4, so the oracle is fed the device's own priors: the comparison is then exact)
     root = np.zeros((T, A), np.float32)
-    root_logits = l0.astype(np.float32)
+    for t in np.nonzero(live)[0]:
+        p = search.pool.read_root_priors(int(t))
+        assert len(p) == n_legal[t]
+        root[t, :len(p)] = p
+    # ... which are masked_policy of the oracle's root logits to within the exp difference
     for t in np.nonzero(live)[0]:
         acts = legal[t, :n_legal[t]]
         m = np.zeros(A, np.float32)
-        m[acts] = np.exp(root_logits[t, acts])
-        root[t] = m / m.sum()
+        m[acts] = np.exp(l0.astype(np.float32)[t, acts])
+        nl = int(n_legal[t])              # child k <- policy[k], positionally (trap T5)
+        np.testing.assert_allclose(root[t, :nl], (m / m.sum())[:nl], rtol=2e-5, atol=1e-7)
     opool.expand_roots(root, legal, n_legal)
     opool.add_root_noise(noise, config.mcts_config.root_exploration_fraction)
-    mism = 0
     for s in range(N):
         p, a = opool.select()
-        mism += int((p != rec.parent[s].cpu().numpy()).sum() + (a != rec.action[s].cpu().numpy()).sum())
+        np.testing.assert_array_equal(p, rec.parent[s].cpu().numpy(), err_msg=f'parent block, simulation {s}')
+        np.testing.assert_array_equal(a, rec.action[s].cpu().numpy(), err_msg=f'action, simulation {s}')
         opool.expand_backprop(priors[s + 1], rec.reward[s].cpu().numpy(), rec.value[s].cpu().numpy())
-    # the root priors come from two different exp implementations (<= 2 ulp apart, trap T4): allow a vanishing
-    # number of near-tie divergences there, none is expected in practice
-    assert mism <= 2, mism
-    if mism == 0:
-        v2, rv2, mm2, pol2 = opool.root_stats()
-        np.testing.assert_array_equal(visits.cpu().numpy(), v2)
-        np.testing.assert_allclose(root_value.cpu().numpy()[live], rv2[live], rtol=1e-12)
-        np.testing.assert_array_equal(chosen.cpu().numpy(), opool.select_action(u, 1.0))
+    v2, rv2, mm2, pol2 = opool.root_stats()
+    np.testing.assert_array_equal(visits.cpu().numpy(), v2)
+    np.testing.assert_array_equal(root_value.cpu().numpy()[live], rv2[live])
+    np.testing.assert_array_equal(policy.cpu().numpy(), pol2)
+    np.testing.assert_array_equal(chosen.cpu().numpy(), opool.select_action(u, 1.0))
+
+
+def test_search_move_rejects_io_that_does_not_match_the_handles():
+    """mz_search_move checks mz_move_io_t against the pool and the network before anything is launched."""
+    import ctypes
+    import torch
+    from muzero_amd import _lib
+    from muzero_amd.exceptions import MuZeroError
+    from muzero_amd.games import cartpole, tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    T, N = 40, 6
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=1)
+    search = LockstepSearch(config, net, num_trees=T)
+    obs = torch.zeros(T, 27, device='cuda')
+    noise = torch.full((T, 9), 1 / 9, dtype=torch.float64, device='cuda')
+    u = torch.zeros(T, dtype=torch.float64, device='cuda')
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    search.run_native(obs, noise, u, temp)                   # the matching call is accepted
+
+    def call(**override):
+        pool = search.pool
+        io = _lib.MoveIO(num_trees=T, num_simulations=N, hidden_size=net.hidden_size, stream=pool._stream,
+                         observation=obs.data_ptr(), noise=noise.data_ptr(), noise_frac=0.25, u=u.data_ptr(),
+                         temperature=temp.data_ptr(), hidden=search.hidden.data_ptr(), logits=search.logits.data_ptr(),
+                         reward=search.reward.data_ptr(), value=search.value.data_ptr(),
+                         parent_block=pool._parent.data_ptr(), action=pool._action.data_ptr(),
+                         out_action=search.out_action.data_ptr())
+        for k, v in override.items():
+            setattr(io, k, v)
+        return _lib.load().mz_search_move(pool._h, net._h, ctypes.byref(io))
+
+    assert call() == 0
+    assert call(num_trees=T + 1) == -1 and b'num_trees' in _lib.load().mz_last_error()
+    assert call(num_simulations=N + 1) == -1 and b'num_simulations' in _lib.load().mz_last_error()
+    assert call(hidden_size=128) == -1 and b'hidden_size' in _lib.load().mz_last_error()
+    other = torch.cuda.Stream()
+    assert call(stream=other.cuda_stream) == -1 and b'stream' in _lib.load().mz_last_error()
+    cart = cartpole.make_config(num_simulations=N)
+    cnet = cart.network_config.network_class(cart, seed=1)
+    pool = search.pool
+    io = _lib.MoveIO(num_trees=T, num_simulations=N, hidden_size=cnet.hidden_size, stream=pool._stream,
+                     observation=obs.data_ptr(), noise=noise.data_ptr(), noise_frac=0.25, u=u.data_ptr(),
+                     temperature=temp.data_ptr(), hidden=search.hidden.data_ptr(), logits=search.logits.data_ptr(),
+                     reward=search.reward.data_ptr(), value=search.value.data_ptr(),
+                     parent_block=pool._parent.data_ptr(), action=pool._action.data_ptr(),
+                     out_action=search.out_action.data_ptr())
+    assert _lib.load().mz_search_move(pool._h, cnet._h, ctypes.byref(io)) == -1       # 2 actions vs the pool's 9
+    assert b'actions' in _lib.load().mz_last_error()
+    with pytest.raises(MuZeroError):
+        LockstepSearch(config, cnet, num_trees=T)
 
 
 class FixtureOutput:

@@ -33,6 +33,29 @@ def test_hip_pool_matches_reference_fixture(name, fused, ad):
     pool.close()
 
 
+@pytest.mark.parametrize('name', [n for n in TREE_FIXTURES if 'choice_weights' in load_golden(n)])
+def test_hip_pool_samples_with_the_reference_weights(name, ad):
+    """softmax_sample at temperatures whose 1/t is no small integer: the pool looks count ** (1/t) up in the table the host
+    registered (mz_pool_set_temperature_table) and draws, for every uniform, the action the reference's random.choices
+    arithmetic draws from the weights the reference itself computed (fixture 'choice_weights')."""
+    from helpers import fixture_temperature, reference_sample
+    fx = load_golden(name)
+    t = fixture_temperature(fx)
+    us = np.concatenate([np.linspace(0.0, 1.0, 400, endpoint=False), [float(fx['u']), np.nextafter(1.0, 0.0)]])
+    T = len(us)
+    pool = hip_pool(**fixture_kwargs(fx, num_trees=T))
+    run_fixture_on_pool(pool, fx, ad, fused=True)            # registers t through TreePool.set_temperature
+    got = ad.get(pool.select_action(ad.put(us), ad.put(np.full(T, t))))
+    want = np.array([reference_sample(fx, float(u)) for u in us])
+    np.testing.assert_array_equal(got, want)
+    # a ninth temperature evicts the oldest table; registering t again brings it back
+    for other in (0.3, 0.6, 0.9, 1.1, 1.3, 1.7, 1.9, 2.3):
+        pool.set_temperature(other)
+    pool.set_temperature(t)
+    np.testing.assert_array_equal(ad.get(pool.select_action(ad.put(us), ad.put(np.full(T, t)))), want)
+    pool.close()
+
+
 CASES = [
     # T, A, N, players, discount, default, bounds, reward_mode, legal_mode      (BASELINE.json configs, reduced T)
     dict(T=64, A=2, N=50, players=1, discount=0.99, default=50.0, bounds=(0.0, 100.0), reward='uniform', legal='all'),
