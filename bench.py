@@ -399,7 +399,7 @@ def main():
     tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
     # the TicTacToe kernels and CartPole's 16-game kernel (batches <= 8192) compute in split-f16 arithmetic
-    split_f16 = with_net and ((wl['net'] == 'tictactoe' and not os.environ.get('MZ_JOB_F32')) or
+    split_f16 = with_net and (wl['net'] == 'tictactoe' or
                               (wl['net'] == 'cartpole' and wl['T'] <= 8192))
     if with_net:
         k1, rest = move.hooks.durations()

@@ -167,13 +167,20 @@ int64_t mz_pool_bytes(mz_pool_t* pool);
 
 typedef enum mz_net_kind {
     MZ_NET_TICTACTOE = 1,   /* reference games/tictactoe.py:151-220 */
-    MZ_NET_CARTPOLE = 2     /* reference games/cartpole.py:63-139  */
+    MZ_NET_CARTPOLE = 2,    /* reference games/cartpole.py:63-139  */
+    MZ_NET_ATARI_SHAPED = 3 /* no reference class: the synthetic network of BASELINE.json configs[3] (18 actions, hidden
+                               state (2,128) = 256 floats, conv-residual dynamics), assembled from the reference's blocks
+                               (one_hot_tensor_encoder network.py:14-40; conv + dense stacks as games/tictactoe.py:188-213);
+                               definition: DESIGN.md and oracle/net_oracle.py AtariShapedOracle */
 } mz_net_kind;
 
 /* Number of f32 weights the flat weight buffer of a network kind holds (layout: DESIGN.md "weights"). */
 int64_t mz_net_num_weights(int32_t kind);
-/* Hidden-state floats per game for a network kind (TicTacToe 3*3*128, CartPole 128). */
+/* Hidden-state floats per game for a network kind (TicTacToe 3*3*128, CartPole 128, Atari-shaped 2*128). */
 int32_t mz_net_hidden_size(int32_t kind);
+/* Action-space size (9, 2, 18) and observation floats per game (27, 4, 256) of a network kind; -1 for an unknown kind. */
+int32_t mz_net_num_actions(int32_t kind);
+int32_t mz_net_observation_size(int32_t kind);
 
 /* Uploads (and re-lays-out for the kernels) a flat f32 weight buffer in Keras order.
  *   weights_host: HOST pointer, mz_net_num_weights(kind) floats;  training_steps: Network.training_steps(). */
@@ -188,7 +195,7 @@ int64_t mz_net_training_steps(mz_net_t* net);
 int mz_net_set_mid_event(mz_net_t* net, void* hip_event);
 
 /* Network.initial_inference (network.py:221-229) fused with split_batch's to_scalar (network.py:165-174).
- *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4);
+ *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4, Atari-shaped 256 = 2x128);
  *   out_hidden  [B, H] f32;  out_value [B] f32 (scalar: identity or support_to_scalar, utils.py:146-148);
  *   out_logits  [B, A] f32;  out_value_raw: NULL or the un-scalarised head ([B,1] or [B,101]). */
 int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden,

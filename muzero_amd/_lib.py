@@ -65,6 +65,8 @@ PROTOTYPES = {
     'mz_pool_bytes': (c_int64, [c_void_p]),
     'mz_net_num_weights': (c_int64, [c_int32]),
     'mz_net_hidden_size': (c_int32, [c_int32]),
+    'mz_net_num_actions': (c_int32, [c_int32]),
+    'mz_net_observation_size': (c_int32, [c_int32]),
     'mz_net_create': (ctypes.c_int, [c_int32, c_void_p, c_int64, c_int64, c_void_p, ctypes.POINTER(c_void_p)]),
     'mz_net_destroy': (ctypes.c_int, [c_void_p]),
     'mz_net_set_stream': (ctypes.c_int, [c_void_p, c_void_p]),

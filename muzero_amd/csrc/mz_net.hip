@@ -1392,6 +1392,314 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_step_kernel(CartDev w, 
                                            out_value, out_logits, nullptr, p, nb);
 }
 
+// ----------------------------------------------------------------------------------------------- Atari-shaped
+// The synthetic network of BASELINE.json configs[3] (18 actions, 256-d hidden state, conv-residual dynamics; defined in
+// oracle/net_oracle.py AtariShapedOracle from the reference's blocks: one_hot_tensor_encoder network.py:14-40, the conv +
+// dense stacks of games/tictactoe.py:188-213).  Hidden state = (2 positions, 128 channels).  A k=3 `same` Conv1D over two
+// positions is, per output position, two 128 x 128 products (position p: taps 1, 2 of inputs 0, 1 for p = 0; taps 0, 1 for
+// p = 1); the 18 one-hot action planes are constant per position and collapse into a [action][position][128] bias table.
+//
+// One 512-thread workgroup runs the WHOLE network for 64 games: nothing but the hidden rows in and the outputs out touches
+// HBM, the 24 weight matrices (1.5 MB, the same for every workgroup, L2-resident) stream through an in-place register
+// ring one stage ahead, and the activations ping-pong between two pairs of LDS tiles:
+//   recurrent: gather -> X;  input conv X -> Y;  2 x { conv a: Y -> X;  conv b (+ residual): X -> Y };  hidden' = Y;
+//              prediction conv Y -> X0;  dense X0 -> X1;  heads X1 -> value, logits;   reward = tanh(<hidden', w> + b)
+//   initial:   observation -> X;  conv X -> Y;  dense (per position) Y -> X = hidden;  prediction from X.
+// 16384 games = 256 workgroups, one per CU.  A stage is the job kernel's (ttt_job_kernel_w): wave v owns output columns
+// 16v .. 16v+15 of all 64 rows as four 16-row blocks on v_mfma_f32_16x16x32_f16, split-f16 operands; one barrier per
+// LAYER (the tiles a layer writes are not the ones it reads).  The residual stream stays in f32 registers (a lane holds
+// four columns of four rows per position), so a residual add is exact f32, never a re-read of a split image.
+struct AtariDev {
+    const float* rec_s;         // recurrent pass: 24 stage matrices (Packer::add_split16) in consumption order:
+                                //   5 conv layers x taps [1, 2, 0, 1] | prediction conv taps 0, 1 | dense | heads (32 columns)
+    const float* ini_s;         // initial pass: conv taps [1, 2, 0, 1] | dense | dense | prediction conv 0, 1 | dense | heads
+    const float* dyn_actbias;   // [18 actions][2 positions][128]: input-conv bias + the action plane's valid taps
+    const float* dyn_bias;      // [4][128]: biases of res1a, res1b, res2a, res2b
+    const float* dyn_reward_w;  // [2][128]
+    const float* rep_conv_b;    // [128]
+    const float* rep_dense_b;   // [128]
+    const float* pred_conv_b;   // [128]
+    const float* pred_dense_b;  // [128]
+    const float* pred_head_b;   // [32]: value bias, 18 policy biases, zeros
+    float dyn_reward_b;
+};
+
+// One 128 x 128 stage: acc[m] += sA[rows 16m .. 16m+15][128] * W[128][this wave's 16 columns] (weights as the row operand:
+// acc[m][i] = column 4 (lane / 16) + i of the wave's 16, row 16 m + lane % 16).  bw holds this stage's fragments and is
+// re-loaded in place with the next stage's (wnext, this lane's slice) as the k-steps retire.
+template <bool LOAD_NEXT>
+__device__ __forceinline__ void stage64(const _Float16* sA, BFragW& bw, const float4* __restrict__ wnext, f32x4 (&acc)[4],
+                                        int n16, int g) {
+    const _Float16* ap = sA + n16 * kLdW + 8 * g;
+    f32x4 acx[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 af[2][4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+        af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the priming reads come first
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
+                af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+            }
+        }
+        const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, af[s & 1][m][0]), al = __builtin_bit_cast(f16x8, af[s & 1][m][1]);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[m], 0, 0, 0);
+            acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[m], 0, 0, 0);
+            acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[m], 0, 0, 0);
+        }
+        if (LOAD_NEXT) {
+            bw.v[2 * s] = wnext[(2 * s) * 512];
+            bw.v[2 * s + 1] = wnext[(2 * s + 1) * 512];
+        }
+        // pin the interleave: the next k-step's eight fragment reads, this k-step's twelve MFMAs, its VMEM reads
+        if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        if (LOAD_NEXT) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
+}
+
+__device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// v[m] = relu(x[m] + bias) of this lane's four columns; split and stored into rows 16 m + n16 of an LDS tile
+__device__ __forceinline__ void store_tile4(const f32x4 (&v)[4], _Float16* tile, int n16, int lcol) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float x[4] = {v[m][0], v[m][1], v[m][2], v[m][3]};
+        uint2 h, l;
+        split4(x, h, l);
+        _Float16* row = tile + (16 * m + n16) * kLdW + lcol;
+        *reinterpret_cast<uint2*>(row) = h;
+        *reinterpret_cast<uint2*>(row + 128) = l;
+    }
+}
+
+constexpr int kAtariStageFloats = 16384;         // one split-f16 128 x 128 matrix = the bytes of 128 x 128 floats
+
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, const float* __restrict__ in_base,
+                                                             const int* __restrict__ parent_block, long block_stride,
+                                                             const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
+                                                             float* __restrict__ out_logits,
+                                                             float* __restrict__ out_value_raw) {
+    constexpr int ROWS = 64;
+    __shared__ __attribute__((aligned(16))) _Float16 sT[4][ROWS * kLdW];      // X0, X1, Y0, Y1
+    __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
+    __shared__ float sOut[ROWS][20];                 // value, 18 logits, reward
+    __shared__ long sRowOff[ROWS];
+    __shared__ int sAct[ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4;
+    const int lcol = wave * 16 + 4 * g;              // this lane's four columns: lcol .. lcol + 3
+    const int row0 = blockIdx.x * ROWS;
+    const float4* wlane = reinterpret_cast<const float4*>(INITIAL ? w.ini_s : w.rec_s) + wave * 64 + lane;
+    BFragW bw;
+    load_bw(bw, INITIAL ? w.ini_s : w.rec_s, lane, wave);
+    if (tid < ROWS) {
+        const int b = row0 + tid;
+        long off = -1;
+        int a = 0;
+        if (b < B) {
+            if (INITIAL) {
+                off = (long)b * 256;
+            } else {
+                const int pb = parent_block ? parent_block[b] : 0;
+                if (pb >= 0) off = (long)pb * block_stride + (long)b * 256;
+                a = action[b];
+                if (a < 0 || a > 17) a = 0;
+            }
+        }
+        sRowOff[tid] = off;
+        sAct[tid] = a;
+    }
+    __syncthreads();
+    {   // the 64 input rows (leaf.parent.hidden_state, agent.py:204, or the observations), 256 floats each -> X0 | X1
+        float4 in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kThreadsW * i, r = idx >> 6, c4 = idx & 63;
+            const long off = sRowOff[r];
+            in[i] = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kThreadsW * i, r = idx >> 6, c4 = idx & 63;
+            const float x[4] = {in[i].x, in[i].y, in[i].z, in[i].w};
+            uint2 h, l;
+            split4(x, h, l);
+            _Float16* row = sT[c4 >> 5] + r * kLdW + (c4 & 31) * 4;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
+        }
+    }
+    const unsigned long long rowmask = __ballot(sRowOff[lane] >= 0);     // rows with an output; this lane's: n16 + 16 m
+    // the residual stream x[position][row block]: first the input conv's per-row bias (conv bias + action planes, the
+    // one-hot encoder's planes being constant per position: network.py:14-40), then the layer outputs
+    f32x4 res[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 bq = INITIAL ? *reinterpret_cast<const float4*>(w.rep_conv_b + lcol)
+                                      : *reinterpret_cast<const float4*>(w.dyn_actbias + (sAct[16 * m + n16] * 2 + p) * 128 + lcol);
+            res[p][m] = f32x4{bq.x, bq.y, bq.z, bq.w};
+        }
+    __syncthreads();
+
+    int stage = 0;                                   // index of the matrix bw holds; the ring loads stage + 1
+    f32x4 acc[4];
+    constexpr int NL = INITIAL ? 1 : 5;
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        const _Float16* src0 = sT[(l & 1) ? 2 : 0];
+        const _Float16* src1 = sT[(l & 1) ? 3 : 1];
+        _Float16* dst[2] = {sT[(l & 1) ? 0 : 2], sT[(l & 1) ? 1 : 3]};
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!INITIAL && l > 0) bq = *reinterpret_cast<const float4*>(w.dyn_bias + (l - 1) * 128 + lcol);
+        const f32x4 bl = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            zero4(acc);
+            stage64<true>(src0, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+            stage64<true>(src1, bw, wlane + (size_t)(stage + 2) * (kAtariStageFloats / 4), acc, n16, g);
+            stage += 2;
+            f32x4 v[4];
+            if (l == 0) {                            // input conv: + bias (+ action planes), relu = x
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + res[p][m], f32x4{0.f, 0.f, 0.f, 0.f});
+            } else if (l & 1) {                      // conv a of a residual block: relu
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bl, f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {                                 // conv b: x = relu(x + conv)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    v[m] = __builtin_elementwise_max(res[p][m] + (acc[m] + bl), f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            if (!(l & 1)) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) res[p][m] = v[m];
+            }
+            store_tile4(v, dst[p], n16, lcol);
+        }
+        __syncthreads();
+    }
+    const _Float16* fin0 = INITIAL ? sT[0] : sT[2];      // the tiles holding the hidden state the prediction reads
+    const _Float16* fin1 = INITIAL ? sT[1] : sT[3];
+    _Float16* tP = INITIAL ? sT[2] : sT[0];
+    _Float16* tD = INITIAL ? sT[3] : sT[1];
+    if (INITIAL) {
+        // Dense 128 -> 128 relu per position = the hidden state: Y -> X
+        const float4 bq = *reinterpret_cast<const float4*>(w.rep_dense_b + lcol);
+        const f32x4 bd = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            zero4(acc);
+            stage64<true>(sT[2 + p], bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+            stage += 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) res[p][m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
+            store_tile4(res[p], sT[p], n16, lcol);
+        }
+        __syncthreads();
+    }
+    {   // hidden state out, f32, from the residual registers; the reward head's partial dot from the same registers
+        float rdot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!INITIAL) rw = *reinterpret_cast<const float4*>(w.dyn_reward_w + p * 128 + lcol);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 x = res[p][m];
+                if ((rowmask >> (16 * m + n16)) & 1ull)
+                    *reinterpret_cast<float4*>(out_hidden + (size_t)(row0 + 16 * m + n16) * 256 + p * 128 + lcol) =
+                        make_float4(x[0], x[1], x[2], x[3]);
+                if (!INITIAL)
+                    rdot[m] = __builtin_fmaf(x[3], rw.w, __builtin_fmaf(x[2], rw.z, __builtin_fmaf(x[1], rw.y, __builtin_fmaf(x[0], rw.x, rdot[m]))));
+            }
+        }
+        if (!INITIAL) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float s = sum_over_g(rdot[m]);
+                if (g == 0) sRew[wave * ROWS + 16 * m + n16] = s;
+            }
+        }
+    }
+    // prediction: Conv1D k=2 valid over the two positions, relu -> P
+    {
+        const float4 bq = *reinterpret_cast<const float4*>(w.pred_conv_b + lcol);
+        const f32x4 bp = {bq.x, bq.y, bq.z, bq.w};
+        zero4(acc);
+        stage64<true>(fin0, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+        stage64<true>(fin1, bw, wlane + (size_t)(stage + 2) * (kAtariStageFloats / 4), acc, n16, g);
+        stage += 2;
+        f32x4 v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bp, f32x4{0.f, 0.f, 0.f, 0.f});
+        store_tile4(v, tP, n16, lcol);
+    }
+    __syncthreads();
+    if (!INITIAL && tid < ROWS) {                    // reward = tanh(<hidden', w> + b)
+        float rs = 0.f;
+#pragma unroll
+        for (int v8 = 0; v8 < 8; ++v8) rs += sRew[v8 * ROWS + tid];
+        sOut[tid][19] = tanhf(rs + w.dyn_reward_b);
+    }
+    {   // Dense 128 -> 128 relu -> D
+        const float4 bq = *reinterpret_cast<const float4*>(w.pred_dense_b + lcol);
+        const f32x4 bd = {bq.x, bq.y, bq.z, bq.w};
+        zero4(acc);
+        stage64<true>(tP, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+        stage += 1;
+        f32x4 v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
+        store_tile4(v, tD, n16, lcol);
+    }
+    __syncthreads();
+    if (wave < 2) {                                  // heads: column 0 = value (tanh), 1 .. 18 = policy logits
+        const float4 bq = *reinterpret_cast<const float4*>(w.pred_head_b + lcol);
+        zero4(acc);
+        stage64<false>(tD, bw, wlane, acc, n16, g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float x[4] = {acc[m][0] + bq.x, acc[m][1] + bq.y, acc[m][2] + bq.z, acc[m][3] + bq.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lcol + i;
+                if (c < 19) sOut[16 * m + n16][c] = c == 0 ? tanhf(x[i]) : x[i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ROWS * 18; idx += kThreadsW) {
+        const int r = idx / 18, o = idx % 18;
+        if (sRowOff[r] >= 0) out_logits[(size_t)(row0 + r) * 18 + o] = sOut[r][1 + o];
+    }
+    if (tid < ROWS && sRowOff[tid] >= 0) {
+        out_value[row0 + tid] = sOut[tid][0];         // to_scalar is the identity (no support)
+        if (out_value_raw) out_value_raw[row0 + tid] = sOut[tid][0];
+        if (!INITIAL) out_reward[row0 + tid] = sOut[tid][19];
+    }
+}
+
 struct Packer {
     std::vector<float> buf;
     size_t add(const float* src, size_t n) {
@@ -1447,6 +1755,8 @@ struct Packer {
 };
 
 constexpr int64_t kTttWeights = 3456 + 128 + 16384 + 128 + 157824 + 128 + 16384 + 128 + 1152 + 1 + 147456 + 128 + 16384 + 128 + 128 + 1 + 1152 + 9;
+constexpr int64_t kAtariWeights = (3 * 128 * 128 + 128) + (128 * 128 + 128) + (3 * 146 * 128 + 128) + 4 * (3 * 128 * 128 + 128) +
+                                  (256 + 1) + (2 * 128 * 128 + 128) + (128 * 128 + 128) + (128 + 1) + (128 * 18 + 18);
 constexpr int64_t kCartWeights = 51712 + 128 + 16384 + 128 + 32768 + 128 + 16384 + 128 + 16384 + 128 + 128 + 1 + 16384 + 128 + 16384 + 128 + 12928 + 101 + 256 + 2;
 
 }  // namespace
@@ -1459,6 +1769,7 @@ struct mz_net {
     float* weights = nullptr;      // one device allocation holding every packed table
     TttDev ttt{};
     CartDev cart{};
+    AtariDev atari{};
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
@@ -1494,16 +1805,28 @@ int launch_status(const char* what) {
 extern "C" {
 
 int64_t mz_net_num_weights(int32_t kind) {
-    return kind == MZ_NET_TICTACTOE ? kTttWeights : kind == MZ_NET_CARTPOLE ? kCartWeights : -1;
+    return kind == MZ_NET_TICTACTOE ? kTttWeights : kind == MZ_NET_CARTPOLE ? kCartWeights
+           : kind == MZ_NET_ATARI_SHAPED ? kAtariWeights : -1;
 }
 
-int32_t mz_net_hidden_size(int32_t kind) { return kind == MZ_NET_TICTACTOE ? 1152 : kind == MZ_NET_CARTPOLE ? 128 : -1; }
+int32_t mz_net_hidden_size(int32_t kind) {
+    return kind == MZ_NET_TICTACTOE ? 1152 : kind == MZ_NET_CARTPOLE ? 128 : kind == MZ_NET_ATARI_SHAPED ? 256 : -1;
+}
+
+int32_t mz_net_num_actions(int32_t kind) {
+    return kind == MZ_NET_TICTACTOE ? 9 : kind == MZ_NET_CARTPOLE ? 2 : kind == MZ_NET_ATARI_SHAPED ? 18 : -1;
+}
+
+int32_t mz_net_observation_size(int32_t kind) {
+    return kind == MZ_NET_TICTACTOE ? 27 : kind == MZ_NET_CARTPOLE ? 4 : kind == MZ_NET_ATARI_SHAPED ? 256 : -1;
+}
 
 int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t training_steps, void* stream,
                   mz_net_t** out_net) {
     MZ_REQUIRE(out_net != nullptr, "out_net is NULL");
     *out_net = nullptr;
-    MZ_REQUIRE(kind == MZ_NET_TICTACTOE || kind == MZ_NET_CARTPOLE, "unknown network kind %d", kind);
+    MZ_REQUIRE(kind == MZ_NET_TICTACTOE || kind == MZ_NET_CARTPOLE || kind == MZ_NET_ATARI_SHAPED, "unknown network kind %d",
+               kind);
     MZ_REQUIRE(wh != nullptr, "weights_host is NULL");
     MZ_REQUIRE(num_weights == mz_net_num_weights(kind), "network kind %d takes %lld weights, got %lld", kind,
                (long long)mz_net_num_weights(kind), (long long)num_weights);
@@ -1628,6 +1951,82 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         add_series(t.dyn_conv_s, 9, [&](int tp) { return pk.add_split16(dyn_conv + (size_t)tp * 137 * 128, 128, 128); });
         put(t.dyn_dense_s, pk.add_split16(dyn_dense, 128, 128));
         add_series(t.pred_conv_s, 9, [&](int c) { return pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128); });
+    } else if (kind == MZ_NET_ATARI_SHAPED) {
+        AtariDev& a = net->atari;
+        const float* rep_conv = take(3 * 128 * 128);   // (3,128,128)
+        const float* rep_conv_b = take(128);
+        const float* rep_dense = take(16384);
+        const float* rep_dense_b = take(128);
+        const float* dyn_conv = take(3 * 146 * 128);   // (3,146,128)
+        const float* dyn_conv_b = take(128);
+        const float* res_k[4];
+        const float* res_b[4];
+        for (int i = 0; i < 4; ++i) {                  // res1a, res1b, res2a, res2b: (3,128,128) + (128)
+            res_k[i] = take(3 * 128 * 128);
+            res_b[i] = take(128);
+        }
+        const float* dyn_reward = take(256);
+        const float* dyn_reward_b = take(1);
+        const float* pred_conv = take(2 * 128 * 128);  // (2,128,128)
+        const float* pred_conv_b = take(128);
+        const float* pred_dense = take(16384);
+        const float* pred_dense_b = take(128);
+        const float* pred_value = take(128);
+        const float* pred_value_b = take(1);
+        const float* pred_policy = take(128 * 18);     // (128,18)
+        const float* pred_policy_b = take(18);
+        std::vector<float> headW(128 * 32, 0.f), headB(32, 0.f);      // [k][32]: value | 18 policy | zeros
+        for (int k = 0; k < 128; ++k) {
+            headW[(size_t)k * 32] = pred_value[k];
+            for (int o = 0; o < 18; ++o) headW[(size_t)k * 32 + 1 + o] = pred_policy[(size_t)k * 18 + o];
+        }
+        headB[0] = pred_value_b[0];
+        for (int o = 0; o < 18; ++o) headB[1 + o] = pred_policy_b[o];
+        // a k=3 `same` conv over two positions: output 0 = in0 @ tap 1 + in1 @ tap 2, output 1 = in0 @ tap 0 + in1 @ tap 1
+        static const int kTapOrder[4] = {1, 2, 0, 1};
+        auto add_conv = [&](const float* k3, int cin) {           // the hidden channels (rows 0..127) of each tap
+            size_t first = 0;
+            for (int i = 0; i < 4; ++i) {
+                const size_t o = pk.add_split16(k3 + (size_t)kTapOrder[i] * cin * 128, 128, 128);
+                if (i == 0) first = o;
+            }
+            return first;
+        };
+        auto add_tail = [&]() {                                    // prediction conv taps 0, 1 | dense | heads
+            pk.add_split16(pred_conv, 128, 128);
+            pk.add_split16(pred_conv + 128 * 128, 128, 128);
+            pk.add_split16(pred_dense, 128, 128);
+            pk.add_split16(headW.data(), 32, 32);
+        };
+        put(a.rec_s, add_conv(dyn_conv, 146));
+        for (int i = 0; i < 4; ++i) add_conv(res_k[i], 128);
+        add_tail();
+        put(a.ini_s, add_conv(rep_conv, 128));
+        pk.add_split16(rep_dense, 128, 128);
+        pk.add_split16(rep_dense, 128, 128);
+        add_tail();
+        std::vector<float> actbias(18 * 2 * 128);
+        for (int act = 0; act < 18; ++act)
+            for (int pos = 0; pos < 2; ++pos)
+                for (int n = 0; n < 128; ++n) {
+                    double sum = dyn_conv_b[n];
+                    for (int j = 0; j < 3; ++j) {
+                        const int in_pos = pos + j - 1;                       // the plane is 1 at every real position
+                        if (in_pos >= 0 && in_pos < 2) sum += dyn_conv[((size_t)j * 146 + 128 + act) * 128 + n];
+                    }
+                    actbias[((size_t)act * 2 + pos) * 128 + n] = (float)sum;
+                }
+        put(a.dyn_actbias, pk.add(actbias));
+        std::vector<float> rb(4 * 128);
+        for (int i = 0; i < 4; ++i) memcpy(rb.data() + i * 128, res_b[i], 128 * sizeof(float));
+        put(a.dyn_bias, pk.add(rb));
+        put(a.dyn_reward_w, pk.add(dyn_reward, 256));
+        put(a.rep_conv_b, pk.add(rep_conv_b, 128));
+        put(a.rep_dense_b, pk.add(rep_dense_b, 128));
+        put(a.pred_conv_b, pk.add(pred_conv_b, 128));
+        put(a.pred_dense_b, pk.add(pred_dense_b, 128));
+        put(a.pred_head_b, pk.add(headB));
+        a.dyn_reward_b = dyn_reward_b[0];
     } else {
         CartDev& c = net->cart;
         const float* rep_conv = take(51712);           // (4,101,128)
@@ -1783,6 +2182,9 @@ static int infer_initial(mz_net_t* net, int32_t batch, const float* observation,
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
                                                           out_value, out_logits, out_value_raw);
+    } else if (net->kind == MZ_NET_ATARI_SHAPED) {
+        atari_kernel<true><<<(batch + 63) / 64, kThreadsW, 0, st>>>(net->atari, batch, observation, nullptr, 0, nullptr,
+                                                                   out_hidden, nullptr, out_value, out_logits, out_value_raw);
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<true><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, observation, nullptr, 0, nullptr,
                                                                          out_hidden, nullptr, out_value, out_logits,
@@ -1845,6 +2247,10 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
         const int nhb = (batch + 15) / 16;
         ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
                                                            out_reward, out_value, out_logits, out_value_raw);
+    } else if (net->kind == MZ_NET_ATARI_SHAPED) {
+        atari_kernel<false><<<(batch + 63) / 64, kThreadsW, 0, st>>>(net->atari, batch, hidden_base, parent_block, bs, action,
+                                                                    out_hidden, out_reward, out_value, out_logits,
+                                                                    out_value_raw);
     } else if (batch <= kCart16MaxBatch) {
         cartpole16_kernel<false><<<(batch + 15) / 16, kThreads16, 0, st>>>(net->cart, batch, hidden_base, parent_block, bs,
                                                                           action, out_hidden, out_reward, out_value,
@@ -1900,9 +2306,7 @@ __attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, int bat
 }
 __attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->hidden_split = false; }
 __attribute__((visibility("hidden"))) int mz_net_hidden_size_of(const mz_net* net) { return mz_net_hidden_size(net->kind); }
-__attribute__((visibility("hidden"))) int mz_net_num_actions_of(const mz_net* net) {
-    return net->kind == MZ_NET_TICTACTOE ? 9 : net->kind == MZ_NET_CARTPOLE ? 2 : -1;
-}
+__attribute__((visibility("hidden"))) int mz_net_num_actions_of(const mz_net* net) { return mz_net_num_actions(net->kind); }
 __attribute__((visibility("hidden"))) hipStream_t mz_net_stream_of(const mz_net* net) { return net->stream; }
 
 int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,

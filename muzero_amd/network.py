@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .exceptions import MuZeroError
 
-MZ_NET_TICTACTOE, MZ_NET_CARTPOLE = 1, 2
+MZ_NET_TICTACTOE, MZ_NET_CARTPOLE, MZ_NET_ATARI_SHAPED = 1, 2, 3
 
 
 def _to_numpy(x):
@@ -322,6 +322,14 @@ def _spec(kind):
                 ('dyn_rdense_k', (128, 128)), ('dyn_rdense_b', (128,)), ('dyn_reward_k', (128, 1)), ('dyn_reward_b', (1,)),
                 ('pred_dense1_k', (128, 128)), ('pred_dense1_b', (128,)), ('pred_dense2_k', (128, 128)), ('pred_dense2_b', (128,)),
                 ('pred_value_k', (128, 101)), ('pred_value_b', (101,)), ('pred_policy_k', (128, 2)), ('pred_policy_b', (2,))]
+    if kind == 'atari':          # the synthetic network of BASELINE.json configs[3] (include/mzhip.h MZ_NET_ATARI_SHAPED)
+        res = [(f'dyn_res{b}{ab}_{kb}', (3, 128, 128) if kb == 'k' else (128,))
+               for b in (1, 2) for ab in 'ab' for kb in 'kb']
+        return ([('rep_conv_k', (3, 128, 128)), ('rep_conv_b', (128,)), ('rep_dense_k', (128, 128)), ('rep_dense_b', (128,)),
+                 ('dyn_conv_k', (3, 146, 128)), ('dyn_conv_b', (128,))] + res +
+                [('dyn_reward_k', (256, 1)), ('dyn_reward_b', (1,)),
+                 ('pred_conv_k', (2, 128, 128)), ('pred_conv_b', (128,)), ('pred_dense_k', (128, 128)), ('pred_dense_b', (128,)),
+                 ('pred_value_k', (128, 1)), ('pred_value_b', (1,)), ('pred_policy_k', (128, 18)), ('pred_policy_b', (18,))])
     raise MuZeroError(f'unknown network kind {kind}')
 
 
@@ -343,3 +351,15 @@ class CartPoleNetwork(Network):
     HIDDEN_SHAPE = (1, 128)
     ACTION_SPACE_SIZE = 2
     VALUE_RAW = 101
+
+
+class AtariShapedNetwork(Network):
+    """The synthetic Atari-shaped network of BASELINE.json configs[3] (no reference class; built from the reference's
+    blocks, see include/mzhip.h MZ_NET_ATARI_SHAPED): observation (2,128), hidden (2,128) = 256 floats, conv-residual
+    dynamics with one-hot action planes, tanh value/reward, 18 logits."""
+    KIND = MZ_NET_ATARI_SHAPED
+    WEIGHT_SPEC = _spec('atari')
+    OBSERVATION_SHAPE = (2, 128)
+    HIDDEN_SHAPE = (2, 128)
+    ACTION_SPACE_SIZE = 18
+    VALUE_RAW = 1

@@ -17,6 +17,10 @@ independent reference for the fp32 HIP kernels; tolerance 1e-5 relative, see tes
   * TicTacToeNetwork          games/tictactoe.py:151-220
   * CartPoleNetwork           games/cartpole.py:63-139
   * initial / recurrent inference graphs   network.py:209-254; split_batch network.py:165-174
+  * AtariShapedOracle: the build's OWN synthetic network for BASELINE.json configs[3] ("18 actions, 256-d hidden
+    state, conv-residual dynamics") -- the reference has no such network; it is assembled from the reference's
+    building blocks (one_hot_tensor_encoder, the conv + dense stacks of games/tictactoe.py:188-213) with Keras
+    semantics, and is the definition the HIP kernels are held to.
 
 Weights are a flat float32 buffer in the order of WEIGHT_SPECS (Keras layer order, kernel then bias), the same
 buffer libmzhip's mz_net_create takes.
@@ -49,7 +53,18 @@ CARTPOLE_SPEC = [
     ('pred_value_k', (128, 101)), ('pred_value_b', (101,)),
     ('pred_policy_k', (128, 2)), ('pred_policy_b', (2,)),
 ]
-WEIGHT_SPECS = {'tictactoe': TICTACTOE_SPEC, 'cartpole': CARTPOLE_SPEC}
+ATARI_SPEC = [      # hidden state (2, 128): two positions x 128 channels = 256 floats; 18 actions
+    ('rep_conv_k', (3, 128, 128)), ('rep_conv_b', (128,)),
+    ('rep_dense_k', (128, 128)), ('rep_dense_b', (128,)),
+    ('dyn_conv_k', (3, 146, 128)), ('dyn_conv_b', (128,)),
+    ('dyn_res1a_k', (3, 128, 128)), ('dyn_res1a_b', (128,)), ('dyn_res1b_k', (3, 128, 128)), ('dyn_res1b_b', (128,)),
+    ('dyn_res2a_k', (3, 128, 128)), ('dyn_res2a_b', (128,)), ('dyn_res2b_k', (3, 128, 128)), ('dyn_res2b_b', (128,)),
+    ('dyn_reward_k', (256, 1)), ('dyn_reward_b', (1,)),
+    ('pred_conv_k', (2, 128, 128)), ('pred_conv_b', (128,)),
+    ('pred_dense_k', (128, 128)), ('pred_dense_b', (128,)),
+    ('pred_value_k', (128, 1)), ('pred_value_b', (1,)), ('pred_policy_k', (128, 18)), ('pred_policy_b', (18,)),
+]
+WEIGHT_SPECS = {'tictactoe': TICTACTOE_SPEC, 'cartpole': CARTPOLE_SPEC, 'atari': ATARI_SPEC}
 CARTPOLE_SCALAR_MIN = np.array([-4.8, -5., -0.418, -5.], np.float32)     # games/cartpole.py:93
 CARTPOLE_SCALAR_MAX = np.array([4.8, 5., 0.418, 5.], np.float32)        # games/cartpole.py:94
 CARTPOLE_SUPPORT = 100                                                   # games/cartpole.py:35
@@ -119,9 +134,12 @@ def conv2d(x, k, b, padding):
     return out + b
 
 
-def conv1d(x, k, b):
-    """x [B,L,Cin], k [kw,Cin,Cout]; valid padding."""
+def conv1d(x, k, b, padding='valid'):
+    """x [B,L,Cin], k [kw,Cin,Cout]; `valid`, or `same` (zero pad (kw-1)//2 left, the rest right, like Keras)."""
     kw = k.shape[0]
+    if padding == 'same':
+        pl = (kw - 1) // 2
+        x = np.pad(x, ((0, 0), (pl, kw - 1 - pl), (0, 0)))
     ol = x.shape[1] - kw + 1
     out = np.zeros((x.shape[0], ol, k.shape[-1]), x.dtype)
     for j in range(kw):
@@ -268,5 +286,60 @@ class CartPoleOracle:
                 logits, value)
 
 
+class AtariShapedOracle:
+    """The synthetic Atari-shaped network of BASELINE.json configs[3] (no counterpart class in the reference; built
+    from its blocks).  observation (2,128); hidden (2,128) = 256 floats; 18 actions; tanh value / reward scalars.
+
+      representation  Conv1D k=3 same 128->128 relu; Dense 128->128 relu (per position)
+      dynamics        one_hot_tensor_encoder(state_shape=(2,), 18) (network.py:14-40) -> (2,146);
+                      Conv1D k=3 same 146->128 relu = x;  two residual blocks  x = relu(x + Conv1D(relu(Conv1D(x))))
+                      (k=3 same 128->128, biases on both) = hidden';  Flatten(256) -> Dense 1 tanh = reward
+      prediction      Conv1D k=2 valid 128->128 relu -> (1,128); Flatten; Dense 128->128 relu; Dense 1 tanh = value;
+                      Dense 18 = logits                         (the shape of games/tictactoe.py:200-213)
+    FLOPs of one recurrent_inference (multiply-adds x 2, only the taps that touch real positions):
+      2 * (4*146*128 + 16*128*128 + 256 + 2*128*128 + 128*128 + 128*19) = 777,472"""
+    kind, A, H = 'atari', 18, 256
+    FLOPS_RECURRENT = 2 * (4 * 146 * 128 + 16 * 128 * 128 + 256 + 2 * 128 * 128 + 128 * 128 + 128 * 19)
+
+    def __init__(self, flat_weights, dtype=np.float64):
+        self.w = unpack(self.kind, flat_weights, dtype)
+        self.dtype = dtype
+
+    def representation(self, obs):
+        w = self.w
+        x = relu(conv1d(np.asarray(obs, self.dtype).reshape(-1, 2, 128), w['rep_conv_k'], w['rep_conv_b'], 'same'))
+        return relu(dense(x, w['rep_dense_k'], w['rep_dense_b']))
+
+    def dynamics(self, hidden, action):
+        w = self.w
+        enc = one_hot_tensor_encoder(np.asarray(hidden, self.dtype).reshape(-1, 2, 128), action, 18)
+        x = relu(conv1d(enc, w['dyn_conv_k'], w['dyn_conv_b'], 'same'))
+        for blk in ('dyn_res1', 'dyn_res2'):
+            y = relu(conv1d(x, w[blk + 'a_k'], w[blk + 'a_b'], 'same'))
+            x = relu(x + conv1d(y, w[blk + 'b_k'], w[blk + 'b_b'], 'same'))
+        reward = np.tanh(dense(x.reshape(-1, 256), w['dyn_reward_k'], w['dyn_reward_b']))
+        return x, reward
+
+    def prediction(self, hidden):
+        w = self.w
+        x = relu(conv1d(hidden, w['pred_conv_k'], w['pred_conv_b'])).reshape(-1, 128)
+        x = relu(dense(x, w['pred_dense_k'], w['pred_dense_b']))
+        value = np.tanh(dense(x, w['pred_value_k'], w['pred_value_b']))
+        logits = dense(x, w['pred_policy_k'], w['pred_policy_b'])
+        return value, logits
+
+    def initial_inference(self, obs):
+        """-> hidden [B,256], value [B] (scalar), logits [B,18], raw value [B,1]"""
+        hidden = self.representation(obs)
+        value, logits = self.prediction(hidden)
+        return hidden.reshape(-1, 256), value[:, 0], logits, value
+
+    def recurrent_inference(self, hidden, action):
+        """-> hidden' [B,256], reward [B], value [B], logits [B,18], raw value [B,1]"""
+        new_hidden, reward = self.dynamics(hidden, action)
+        value, logits = self.prediction(new_hidden)
+        return new_hidden.reshape(-1, 256), reward[:, 0], value[:, 0], logits, value
+
+
 def make_oracle(kind, flat_weights, dtype=np.float64):
-    return {'tictactoe': TicTacToeOracle, 'cartpole': CartPoleOracle}[kind](flat_weights, dtype)
+    return {'tictactoe': TicTacToeOracle, 'cartpole': CartPoleOracle, 'atari': AtariShapedOracle}[kind](flat_weights, dtype)

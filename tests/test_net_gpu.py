@@ -14,9 +14,9 @@ RTOL, ATOL = 1e-5, 1e-5
 
 
 def make(kind, seed=11):
-    from muzero_amd.network import CartPoleNetwork, TicTacToeNetwork
+    from muzero_amd.network import AtariShapedNetwork, CartPoleNetwork, TicTacToeNetwork
     flat = no.random_weights(kind, seed)
-    cls = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork}[kind]
+    cls = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork, 'atari': AtariShapedNetwork}[kind]
     return cls(config=None, weights=flat), no.make_oracle(kind, flat)
 
 
@@ -26,6 +26,8 @@ def observations(kind, B, rng):
         to_play = rng.integers(0, 2, size=(B, 1, 1))
         obs = np.stack([(board == 0), (board == 1), np.broadcast_to(to_play, (B, 3, 3))], -1).astype(np.float32)
         return obs.reshape(B, 27)
+    if kind == 'atari':
+        return rng.standard_normal((B, 256)).astype(np.float32)
     span = np.array([2.4, 3.0, 0.21, 3.0], np.float32)
     return (rng.uniform(-1, 1, size=(B, 4)) * span).astype(np.float32)
 
@@ -35,7 +37,7 @@ def close(got, want, scale=1.0):
 
 
 @pytest.mark.parametrize('B', [1, 63, 64, 65, 200])
-@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole', 'atari'])
 def test_initial_and_recurrent_inference(kind, B):
     net, ref = make(kind)
     rng = np.random.default_rng(B)
@@ -91,7 +93,7 @@ def test_cartpole_large_batch_takes_the_row_tile_kernel():
     close(out2.batch_value, raw2)
 
 
-@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole', 'atari'])
 def test_pool_gather_path_and_inactive_rows(kind):
     """recurrent_inference reading leaf.parent.hidden_state rows by parent block from the [N+1][T][H] tensor and
     writing block 3 in place; rows with parent_block < 0 are left untouched."""
@@ -135,9 +137,10 @@ def test_host_to_scalar_matches_fused_epilogue():
 
 def test_weight_count_and_checkpoint_round_trip(tmp_path):
     from muzero_amd.exceptions import MuZeroError
-    from muzero_amd.network import CartPoleNetwork, TicTacToeNetwork
+    from muzero_amd.network import AtariShapedNetwork, CartPoleNetwork, TicTacToeNetwork
     assert TicTacToeNetwork.num_weights() == no.num_weights('tictactoe')
     assert CartPoleNetwork.num_weights() == no.num_weights('cartpole')
+    assert AtariShapedNetwork.num_weights() == no.num_weights('atari')
     net, _ = make('tictactoe')
     obs = observations('tictactoe', 8, np.random.default_rng(1))
     before = net.initial_inference(obs).batch_policy_logits.cpu().numpy()

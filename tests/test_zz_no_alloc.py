@@ -24,15 +24,16 @@ def _call(lib, fn, net, pool, parent, action, block):
     return status, {k: v.cpu().numpy() for k, v in out.items()}
 
 
-@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole'])
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole', 'atari'])
 def test_noalloc_equals_recurrent_inference_two_calls_in_a_row(kind):
     import torch
     from muzero_amd import _lib
-    from muzero_amd.network import CartPoleNetwork, TicTacToeNetwork
+    from muzero_amd.network import AtariShapedNetwork, CartPoleNetwork, TicTacToeNetwork
     from oracle import net_oracle as no
     lib = _lib.load()
     flat = no.random_weights(kind, 17)
-    net = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork}[kind](config=None, weights=flat)
+    net = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork, 'atari': AtariShapedNetwork}[kind](config=None,
+                                                                                                      weights=flat)
     ref = no.make_oracle(kind, flat)
     rng = np.random.default_rng(8)
     for T in (700, 130):                         # the second call is smaller: stale scratch rows lie beyond it
