@@ -35,7 +35,8 @@ WORKLOADS = {
                               net='tictactoe', reward='tanh'),
     'cartpole_1024x50': dict(T=1024, A=2, N=50, players=1, discount=0.99, default=50.0, bounds=(0.0, 100.0),
                              net='cartpole', reward='uniform'),
-    'atari_16384x50': dict(T=16384, A=18, N=50, players=1, discount=0.997, default=0.0, bounds=None, net=None,
+    # configs[3]: conv-residual dynamics network in the loop (--inject: tree kernels alone, injected outputs)
+    'atari_16384x50': dict(T=16384, A=18, N=50, players=1, discount=0.997, default=0.0, bounds=None, net='atari',
                            reward='uniform'),
     'go_2048x800': dict(T=2048, A=362, N=800, players=2, discount=1.0, default=0.0, bounds=(-1.0, 1.0), net=None,
                         reward='zero'),
@@ -214,9 +215,9 @@ class NetworkMove:
     bound = 'mfma'
 
     def __init__(self, wl, device, seed, world, lanes=1, event_stride=5):
-        from muzero_amd.games import cartpole, tictactoe
+        from muzero_amd.games import atari_shaped, cartpole, tictactoe
         from muzero_amd.selfplay import LockstepSearch, PipelinedSearch, TrajectoryGather
-        mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[wl['net']]
+        mod = {'tictactoe': tictactoe, 'cartpole': cartpole, 'atari': atari_shaped}[wl['net']]
         self.wl = wl
         self.config = mod.make_config(num_simulations=wl['N'])
         self.net = self.config.network_config.network_class(self.config, seed=7)       # random-init (glorot) weights
@@ -240,6 +241,12 @@ class NetworkMove:
             # SURVEY.md 8(d) terms this kernel covers per evaluation: conv 49*137*128, dense 9*128*128,
             # reward 1152, prediction conv 9*128*128 (multiply-adds x2)
             self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
+        elif wl['net'] == 'atari':       # synthetic (2,128) observations
+            self.obs = torch.randn(T, 256, generator=g, device=device).contiguous()
+            self.dominant = 'atari_kernel'
+            # the whole network is one launch: input conv 4 taps x 146 x 128, 16 + 2 + 1 128x128 stages,
+            # reward 256, heads 128 x 19
+            self.flops_per_eval = 2 * (4 * 146 * 128 + 16 * 128 * 128 + 256 + 2 * 128 * 128 + 128 * 128 + 128 * 19)
         else:
             span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
             self.obs = ((torch.rand(T, 4, generator=g, device=device) * 2 - 1) * span).contiguous()
@@ -282,49 +289,59 @@ def measured_traffic(workload, kernel):
     return row['traffic_bytes_per_launch'], os.path.basename(files[-1])
 
 
-def cpu_baseline(wl, seconds):
-    """The CPU oracle -- a port of the reference's Python MCTS (oracle/mcts_oracle.py) calling the numpy network
-    port (oracle/net_oracle.py, float32, batch 1 per simulation like agent.py:204-207) -- on ONE host core, same
-    shapes, for about `seconds` of CPU work.  Workloads without a network time the tree alone."""
-    from oracle import mcts_oracle, net_oracle
-    A, N = wl['A'], wl['N']
-    rng = np.random.Generator(np.random.PCG64(99))
-    net = None
-    if wl['net']:
-        net = net_oracle.make_oracle(wl['net'], net_oracle.random_weights(wl['net'], 7), dtype=np.float32)
-    sims, moves = 0, 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        tree = mcts_oracle.TreeOracle(A, N, wl['players'], wl['discount'], wl['default'], wl['bounds'])
-        if net is not None:
-            if wl['net'] == 'tictactoe':
-                obs = rng.integers(0, 2, size=(1, 27)).astype(np.float32)
-            else:
-                obs = (rng.uniform(-1, 1, size=(1, 4)) * [2.4, 3.0, 0.21, 3.0]).astype(np.float32)
-            hidden, _, logits, _ = net.initial_inference(obs)
-            hiddens = [hidden]
-            tree.expand_root(mcts_oracle.masked_policy_f32(logits[0], range(A)), range(A))
-        else:
-            logits = rng.standard_normal((N + 1, A)).astype(np.float32)
-            values = np.tanh(rng.standard_normal(N + 1)).astype(np.float32)
-            rewards = rng.random(N + 1).astype(np.float32)
-            tree.expand_root(mcts_oracle.masked_policy_f32(logits[0], range(A)), range(A))
-        tree.add_root_noise(rng.dirichlet([1.0] * A), 0.25)
-        for s in range(N):
-            parent, action = tree.select()
-            if net is not None:
-                h, r, v, lg, _ = net.recurrent_inference(hiddens[parent], np.array([action]))
-                hiddens.append(h)
-                tree.expand_backprop(mcts_oracle.masked_policy_f32(lg[0], range(A)), r[0], v[0])
-            else:
-                tree.expand_backprop(mcts_oracle.masked_policy_f32(logits[s + 1], range(A)), rewards[s + 1], values[s + 1])
-        tree.select_action(float(rng.random()), 1.0)
-        sims += N
-        moves += 1
-    dt = time.perf_counter() - t0
-    what = 'python tree oracle + numpy fp32 network oracle at batch 1' if net is not None else 'python tree oracle only'
-    return dict(value=sims / dt, unit='simulations/s', cores=1, kind='port',
-                sample=f'{moves} single-game moves x {N} simulations, A={A}, {what}, {dt:.1f} s')
+def profiled_stats(workload, kernel):
+    """Duration statistics of `kernel` from the committed rocprofv3 kernel trace of this workload
+    (profiles/*_kernel_medians_<workload>.json, made by tools/profile_workload.sh from `rocprofv3 --kernel-trace`), with the
+    ms_per_step the profiled run itself printed: the figures the live HIP-event average should agree with."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*_kernel_medians_{workload}.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    rows = [dict(row, name=name) for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
+    if not rows:
+        return None
+    row = max(rows, key=lambda r: r['calls'])
+    return {'kernel': row['name'], 'median_us': row['median_us'], 'mean_us': row['mean_us'], 'min_us': row['min_us'],
+            'calls': row['calls'], 'ms_per_step_under_rocprof': data.get('ms_per_step'), 'source': os.path.basename(files[-1])}
+
+
+def host_cores():
+    """Cores this process may use: the GPU box exports its per-GPU share as OMP_NUM_THREADS (os.cpu_count() there counts
+    the whole machine); elsewhere the visible CPUs."""
+    share = int(os.environ.get('OMP_NUM_THREADS', '0') or 0)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return max(1, min(visible, share) if share > 0 else visible)
+
+
+def cpu_baseline(wl, seconds, cores=None):
+    """The CPU oracle -- a port of the reference's Python MCTS (oracle/mcts_oracle.py) calling the numpy network port
+    (oracle/net_oracle.py, float32, batch 1 per simulation like agent.py:204-207) -- one single-threaded process per host
+    core (oracle/cpu_bench.py), same shapes, each for about `seconds`.  value = the sum of the workers'
+    rates.  Workloads without a network time the tree alone."""
+    import subprocess
+    cores = cores or host_cores()
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), '--actions', str(wl['A']), '--simulations',
+           str(wl['N']), '--players', str(wl['players']), '--discount', str(wl['discount']), '--default-value',
+           str(wl['default']), '--net', wl['net'] or 'none', '--seconds', str(seconds)]
+    if wl['bounds'] is not None:
+        cmd += ['--bounds', str(wl['bounds'][0]), str(wl['bounds'][1])]
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    procs = [subprocess.Popen(cmd + ['--seed', str(99 + i)], stdout=subprocess.PIPE, env=env, text=True)
+             for i in range(cores)]
+    rows = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=seconds * 10 + 120)
+        if pr.returncode != 0:
+            raise RuntimeError(f'cpu_baseline worker failed with {pr.returncode}')
+        rows.append(json.loads(out.strip().splitlines()[-1]))
+    rate = sum(r['simulations'] / r['seconds'] for r in rows)
+    moves = sum(r['moves'] for r in rows)
+    what = ('python tree oracle + numpy fp32 network oracle at batch 1' if wl['net'] else 'python tree oracle only')
+    return dict(value=rate, unit='simulations/s', cores=cores, kind='port', per_core=rate / cores,
+                sample=f"{moves} single-game moves x {wl['N']} simulations over {cores} single-threaded processes, "
+                       f"A={wl['A']}, {what}, {max(r['seconds'] for r in rows):.1f} s each")
 
 
 def main():
@@ -337,6 +354,9 @@ def main():
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="weak: the workload's games PER GPU (default); strong: the workload's games in total, sharded "
+                         "over the ranks (BASELINE.json configs[2] read as 4096 games over 1/2/4/8 GPUs)")
     ap.add_argument('--lanes', type=int, default=1,
                     help='split the games of a GPU into this many lockstep lanes on separate HIP streams')
     ap.add_argument('--event-every', type=int, default=4,
@@ -360,6 +380,10 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.trees:
         wl['T'] = args.trees
+    if args.scaling == 'strong' and world > 1:       # the same games in total, a contiguous shard per rank
+        from muzero_amd.selfplay import shard_bounds
+        lo, hi = shard_bounds(wl['T'], rank, world)
+        wl['T'] = hi - lo
     with_net = wl['net'] is not None and not args.inject
     # per-rank seeds: every rank searches different games
     stride = max(1, min(args.event_stride, wl['N'] // 4))
@@ -394,13 +418,16 @@ def main():
     sims_rank = int(c1[0] - c0[0])
     sum_d = int(c1[1] - c0[1])
     assert sims_rank == args.steps * wl['T'] * wl['N'], (sims_rank, args.steps, wl['T'], wl['N'])
-    total_sims = sims_rank * world
+    total_sims = sims_rank
+    if world > 1:                                    # ranks hold equal shards under weak scaling, near-equal under strong
+        tot = torch.tensor([sims_rank], dtype=torch.int64, device=device)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_sims = int(tot.item())
     mean_d = sum_d / sims_rank
     tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
     extra = {}
-    # the TicTacToe kernels and CartPole's 16-game kernel (batches <= 8192) compute in split-f16 arithmetic
-    split_f16 = with_net and (wl['net'] == 'tictactoe' or
-                              (wl['net'] == 'cartpole' and wl['T'] <= 8192))
+    # every network kernel but CartPole's large-batch one (batches > 8192) computes in split-f16 arithmetic
+    split_f16 = with_net and not (wl['net'] == 'cartpole' and wl['T'] > 8192)
     if with_net:
         k1, rest = move.hooks.durations()
         flops_launch = move.trees_per_launch * move.flops_per_eval
@@ -418,12 +445,15 @@ def main():
                     'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
-                    'executed_mfma_tflops': executed, 'executed_frac': executed / peak,
-                    'f32_equivalent': {'peak': F32_MFMA_PEAK_TFLOPS, 'frac': achieved / F32_MFMA_PEAK_TFLOPS}}
+                    'executed_mfma_tflops': executed, 'executed_frac': executed / peak}
         rest_name = ('head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else
                      'after_fused_kernel_us' if move.dominant == 'cartpole16_step_kernel' else 'tree_step_kernel_us')
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
+        if rest_name == 'tree_step_kernel_us':       # the tree step is a launch of its own: its HBM roofline beside it
+            extra['tree_step_roofline'] = {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': tree_bytes_launch / rest / 1e9,
+                                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                           'frac': tree_bytes_launch / rest / 1e9 / HBM_PEAK_GBS, 'avg_launch_us': rest * 1e6}
         network = f"{wl['net']} network, random-init weights, f32 results (1e-5 of the fp64 oracle)"
     else:
         avg = move.step_durations()
@@ -443,7 +473,7 @@ def main():
         out = {
             'metric': 'mcts_simulations_per_sec', 'value': total_sims / elapsed, 'unit': 'simulations/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32 via split-f16 MFMA' if split_f16 else 'f32') if with_net else 'f64',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': ('f32 via split-f16 MFMA' if split_f16 else 'f32') if with_net else 'f64',
             'data': 'synthetic',
             'config': {'workload': args.workload, 'trees_per_gpu': wl['T'], 'lanes_per_gpu': args.lanes,
                        'actions': wl['A'],
@@ -452,6 +482,8 @@ def main():
                                    (', per-move all-gather of search statistics' if world > 1 and with_net else '')},
             'roofline': roofline,
         }
+        if args.trees is None and args.lanes == 1:
+            out['roofline']['rocprof'] = profiled_stats(args.workload, move.dominant)
         out.update(extra)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl if with_net else dict(wl, net=None), args.cpu_seconds)

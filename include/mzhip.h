@@ -272,6 +272,14 @@ typedef struct mz_move_io {
                                       its two launches (if it has two), [4s+2] after the tree step -- which shares the
                                       second launch for the TicTacToe network, so [4s+1]..[4s+2] spans head + tree step
                                       there; [4s+3] is unused.  A record costs ~13 us of stream time: sample sparsely */
+    /* Optional search trace (tests, debugging; every pointer NULL = off, all five non-NULL = on): what simulation s
+     * fed to and got from the network is kept in row s instead of being overwritten in the one-row workspaces above.
+     * The launches are the same, only their output pointers differ. */
+    float* trace_reward;           /* [N, T] f32 */
+    float* trace_value;            /* [N, T] f32 */
+    float* trace_logits;           /* [N, T, A] f32 */
+    int32_t* trace_parent;         /* [N, T] i32: block of leaf.parent of simulation s (-1: inactive tree) */
+    int32_t* trace_action;         /* [N, T] i32: the action leading to the leaf */
 } mz_move_io_t;
 
 /* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in

@@ -27,7 +27,9 @@ class MoveIO(ctypes.Structure):
                 ('hidden', c_void_p), ('logits', c_void_p), ('reward', c_void_p), ('value', c_void_p),
                 ('parent_block', c_void_p), ('action', c_void_p), ('out_visits', c_void_p),
                 ('out_root_value', c_void_p), ('out_minmax', c_void_p), ('out_policy', c_void_p),
-                ('out_action', c_void_p), ('events', c_void_p)]
+                ('out_action', c_void_p), ('events', c_void_p),
+                ('trace_reward', c_void_p), ('trace_value', c_void_p), ('trace_logits', c_void_p),
+                ('trace_parent', c_void_p), ('trace_action', c_void_p)]
 
 
 class ReplayConfig(ctypes.Structure):

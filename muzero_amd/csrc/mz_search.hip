@@ -23,8 +23,14 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
                pool->dev.A);
     MZ_REQUIRE(static_cast<hipStream_t>(io->stream) == pool->stream, "mz_move_io_t.stream is not the pool's stream");
     MZ_REQUIRE(mz_net_stream_of(net) == pool->stream, "net and pool must launch on the same stream");
+    const int ntrace = (io->trace_reward != nullptr) + (io->trace_value != nullptr) + (io->trace_logits != nullptr) +
+                       (io->trace_parent != nullptr) + (io->trace_action != nullptr);
+    MZ_REQUIRE(ntrace == 0 || ntrace == 5, "the five trace_* pointers of mz_move_io_t must be all NULL or all set");
+    const bool trace = ntrace == 5;
     const int T = io->num_trees, N = io->num_simulations;
     const int64_t H = io->hidden_size;
+    const size_t A = (size_t)pool->dev.A;
+    hipStream_t st = pool->stream;
     void** ev = io->events;
 #define MZ_TRY_(expr)               \
     do {                            \
@@ -48,8 +54,17 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         } else if (ev) {
             MZ_TRY_(mz_net_set_mid_event(net, nullptr));
         }
+        if (trace) {      // this simulation's selection, before the fused step overwrites it with the next one
+            MZ_HIP(hipMemcpyAsync(io->trace_parent + (size_t)s * T, io->parent_block, (size_t)T * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, st));
+            MZ_HIP(hipMemcpyAsync(io->trace_action + (size_t)s * T, io->action, (size_t)T * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, st));
+        }
         MZ_TRY_(mz_infer_recurrent_step(net, pool, s + 1 < N, io->hidden, io->parent_block, (int64_t)T * H, io->action,
-                                        io->hidden + (size_t)(s + 1) * T * H, io->reward, io->value, io->logits));
+                                        io->hidden + (size_t)(s + 1) * T * H,
+                                        trace ? io->trace_reward + (size_t)s * T : io->reward,
+                                        trace ? io->trace_value + (size_t)s * T : io->value,
+                                        trace ? io->trace_logits + (size_t)s * T * A : io->logits));
         if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));

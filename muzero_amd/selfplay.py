@@ -69,10 +69,11 @@ class LockstepSearch:
         _check_tensor('out action', self.out_action, torch.int32, (self.T,), self.device)
         self.native = isinstance(network, Network)
 
-    def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None):
+    def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None, trace=None):
         """The whole move enqueued by one C call (mz_search_move): same launches as run(), no interpreter time
-        between them.  `events`: optional ctypes array of 4*N hipEvent_t (measurement).  Results are written to the
-        search's own out_* tensors, which are returned."""
+        between them.  `events`: optional ctypes array of 4*N hipEvent_t (measurement).  `trace`: optional dict that
+        receives the per-simulation network outputs and selections (reward/value [N,T], logits [N,T,A], parent/action
+        [N,T]; mz_move_io_t.trace_*).  Results are written to the search's own out_* tensors, which are returned."""
         if not self.native:
             raise MuZeroError('run_native needs a HIP-backed muzero_amd.network.Network')
         pool, net, dev = self.pool, self.network, self.device
@@ -93,6 +94,14 @@ class LockstepSearch:
             out_minmax=self.out_minmax.data_ptr(), out_policy=self.out_policy.data_ptr(),
             out_action=self.out_action.data_ptr(),
             events=None if events is None else ctypes.cast(events, ctypes.c_void_p))
+        if trace is not None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            trace.update(reward=torch.zeros(self.N, self.T, **f32), value=torch.zeros(self.N, self.T, **f32),
+                         logits=torch.zeros(self.N, self.T, self.A, **f32), parent=torch.zeros(self.N, self.T, **i32),
+                         action=torch.zeros(self.N, self.T, **i32))
+            io.trace_reward, io.trace_value, io.trace_logits = (trace[k].data_ptr() for k in ('reward', 'value', 'logits'))
+            io.trace_parent, io.trace_action = trace['parent'].data_ptr(), trace['action'].data_ptr()
         _lib.check(_lib.load().mz_search_move(pool._h, net._h, ctypes.byref(io)))
         return self.out_visits, self.out_root_value, self.out_minmax, self.out_policy, self.out_action
 

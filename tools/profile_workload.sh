@@ -14,6 +14,8 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt -o out --output-fo
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o out --output-format csv -- python3 $BENCH --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_f.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o out --output-format csv -- python3 $BENCH --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_w.log 2>&1
 cp $(find $O/kt -name out_kernel_stats.csv) $O/kernel_stats.csv
+python3 tools/kt_summary.py $W $(find $O/kt -name out_kernel_trace.csv) $O/kt.log $O/kernel_medians.json \
+    "rocprofv3 --kernel-trace --stats -- python3 $BENCH --steps 5 --warmup 2 --no-cpu-baseline"
 python3 tools/pmc_to_json.py $W $(find $O/pmc_f -name out_counter_collection.csv) $(find $O/pmc_w -name out_counter_collection.csv) \
     $O/hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 $BENCH --steps 2 --warmup 1 --no-cpu-baseline"
 rm -rf $O/pmc_f $O/pmc_w $O/kt
