@@ -337,6 +337,50 @@ int mz_env_cartpole_observe(void* stream, int32_t num_games, const double* state
 int mz_env_cartpole_step(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
                          const int32_t* action, float* out_reward, int32_t* out_status, int32_t* any_illegal);
 
+/* Restart of the games with where[g] != 0 only (every other game is left as it is): a finished self-play slot starts
+ * its next game while the others play on, like the reference's agent loop (agent_services.py:47-48). */
+int mz_env_ttt_reset_where(void* stream, int32_t num_games, int8_t* board, int32_t* to_play, int32_t* steps, int32_t* ended,
+                           const int32_t* where);
+int mz_env_cartpole_reset_where(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
+                                const double* initial_state, const int32_t* where);
+
+/* ---- game histories of G self-play slots and the hand-over of finished games -------- *
+ * GameHistory (reference game.py:8-41) for G concurrent games as padded move-major device arrays, M = move capacity:
+ *   observations [M+1,G,obs] f32 | to_plays [M+1,G] i32 | actions [M,G] i32 | rewards [M,G] f32 | root_values [M,G] f64 |
+ *   policies [M,G,A] f32 | lengths [G] i32.
+ * Slots advance independently: slot g is at move steps[g] of ITS game (the environment's step counter).
+ *   record_observation: observation/to_play of every slot -> row steps[g] (Game.__init__/apply, game.py:52-61,66-71);
+ *   record_move: for slots whose step succeeded (status[g] == 0), with steps already advanced by the step:
+ *                action, reward, root value, policy -> row steps[g]-1 (game.py:66-75);
+ *   flush: slots whose game is over (ended[g] != 0, or steps[g] == M: agent.py:34's max_moves) hand their history to the
+ *          `finished` store, column = the game's serial number (serial [G] i32; games with serial >= the store's
+ *          num_games are dropped), and receive the next free serials in slot order; counters [2] i64 = {next serial,
+ *          games stored}; flush_dst [G] i32 (workspace) and reset_mask [G] i32 (1 where the slot must be restarted:
+ *          pass it to the environment's reset_where).  What the reference's agent does between two games:
+ *          remote_replay_buffer.save_history(history), then the next play_game (agent_services.py:47-54). */
+typedef struct mz_history {
+    int32_t num_games, max_moves, observation_size, num_actions;
+    float* observations;
+    int32_t* to_plays;
+    int32_t* actions;
+    float* rewards;
+    double* root_values;
+    float* policies;
+    int32_t* lengths;
+} mz_history_t;
+int mz_history_record_observation(void* stream, const mz_history_t* hist, const int32_t* steps, const float* observation,
+                                  const int32_t* to_play);
+int mz_history_record_move(void* stream, const mz_history_t* hist, const int32_t* steps, const int32_t* status,
+                           const int32_t* action, const float* reward, const double* root_value, const float* policy);
+int mz_history_flush(void* stream, const mz_history_t* live, const mz_history_t* finished, const int32_t* steps,
+                     const int32_t* ended, int32_t* serial, int64_t* counters, int32_t* flush_dst, int32_t* reset_mask);
+
+/* The root noise of a batch of games from independent Gamma(alpha, 1) draws (the caller's RNG): out_noise[g, k] =
+ * gamma[g, k] / sum(gamma[g, 0..n_legal[g])) for k < n_legal[g], else 0 -- np.random.dirichlet([alpha] * n_children)
+ * (agent.py:172) for every game in one launch, in the layout mz_add_root_noise / mz_search_move take.  [G, A] f64. */
+int mz_dirichlet_from_gamma(void* stream, int32_t num_games, int32_t num_actions, const double* gamma,
+                            const int32_t* n_legal, double* out_noise);
+
 /* ---- replay-side training targets (the step after the path) -------------------------------- *
  * ReplayBuffer.preprocess_history + compute_target_value (reference replay_buffer.py:66-99) for G finished games
  * held as padded move-major arrays (muzero_amd.selfplay.BatchedHistory), M = move capacity, K = num_unroll_steps:

@@ -32,6 +32,13 @@ class MoveIO(ctypes.Structure):
                 ('trace_parent', c_void_p), ('trace_action', c_void_p)]
 
 
+class History(ctypes.Structure):
+    """mz_history_t"""
+    _fields_ = [('num_games', c_int32), ('max_moves', c_int32), ('observation_size', c_int32), ('num_actions', c_int32),
+                ('observations', c_void_p), ('to_plays', c_void_p), ('actions', c_void_p), ('rewards', c_void_p),
+                ('root_values', c_void_p), ('policies', c_void_p), ('lengths', c_void_p)]
+
+
 class ReplayConfig(ctypes.Structure):
     """mz_replay_config_t"""
     _fields_ = [('num_games', c_int32), ('max_moves', c_int32), ('num_actions', c_int32), ('num_unroll_steps', c_int32),
@@ -91,6 +98,12 @@ PROTOTYPES = {
                                        c_void_p, c_void_p]),
     'mz_env_cartpole_reset': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_env_cartpole_observe': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_ttt_reset_where': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_env_cartpole_reset_where': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_history_record_observation': (ctypes.c_int, [c_void_p, ctypes.POINTER(History), c_void_p, c_void_p, c_void_p]),
+    'mz_history_record_move': (ctypes.c_int, [c_void_p, ctypes.POINTER(History)] + [c_void_p] * 6),
+    'mz_dirichlet_from_gamma': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'mz_history_flush': (ctypes.c_int, [c_void_p, ctypes.POINTER(History), ctypes.POINTER(History)] + [c_void_p] * 6),
     'mz_replay_targets': (ctypes.c_int, [c_void_p, ctypes.POINTER(ReplayConfig)] + [c_void_p] * 12),
     'mz_env_cartpole_step': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),

@@ -28,6 +28,17 @@ __global__ void ttt_reset_kernel(int T, signed char* board, int* to_play, int* s
     ended[t] = 0;
 }
 
+// reset of the games with where[t] != 0 only (a finished slot is restarted while the others play on)
+__global__ void ttt_reset_where_kernel(int T, signed char* board, int* to_play, int* steps, int* ended, const int* where) {
+    const int t = blockIdx.x * kEnvThreads + threadIdx.x;
+    if (t >= T || where[t] == 0) return;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) board[(size_t)t * 9 + c] = -1;
+    to_play[t] = 0;
+    steps[t] = 0;
+    ended[t] = 0;
+}
+
 // _get_state (games/tictactoe.py:107-111): planes [board == 0, board == 1, to_play] stacked on the last axis.
 __global__ void ttt_observe_kernel(int T, const signed char* board, const int* to_play, const int* ended,
                                    float* obs, int* legal, int* n_legal) {
@@ -103,6 +114,16 @@ __global__ void ttt_step_kernel(int T, signed char* board, int* to_play, int* st
 __global__ void cartpole_reset_kernel(int T, double* state, int* steps, int* ended, const double* init) {
     const int t = blockIdx.x * kEnvThreads + threadIdx.x;
     if (t >= T) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) state[(size_t)t * 4 + i] = init[(size_t)t * 4 + i];
+    steps[t] = 0;
+    ended[t] = 0;
+}
+
+__global__ void cartpole_reset_where_kernel(int T, double* state, int* steps, int* ended, const double* init,
+                                            const int* where) {
+    const int t = blockIdx.x * kEnvThreads + threadIdx.x;
+    if (t >= T || where[t] == 0) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) state[(size_t)t * 4 + i] = init[(size_t)t * 4 + i];
     steps[t] = 0;
@@ -187,6 +208,16 @@ int mz_env_ttt_reset(void* stream, int32_t num_games, int8_t* board, int32_t* to
     return env_launch_status("mz_env_ttt_reset");
 }
 
+int mz_env_ttt_reset_where(void* stream, int32_t num_games, int8_t* board, int32_t* to_play, int32_t* steps, int32_t* ended,
+                           const int32_t* where) {
+    MZ_REQUIRE(num_games >= 0, "num_games must be >= 0 (got %d)", num_games);
+    if (num_games == 0) return MZ_OK;
+    MZ_REQUIRE(board && to_play && steps && ended && where, "board/to_play/steps/ended/where is NULL");
+    ttt_reset_where_kernel<<<env_grid(num_games), kEnvThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        num_games, reinterpret_cast<signed char*>(board), to_play, steps, ended, where);
+    return env_launch_status("mz_env_ttt_reset_where");
+}
+
 int mz_env_ttt_observe(void* stream, int32_t num_games, const int8_t* board, const int32_t* to_play,
                        const int32_t* ended, float* out_observation, int32_t* out_legal, int32_t* out_n_legal) {
     MZ_REQUIRE(num_games >= 0, "num_games must be >= 0 (got %d)", num_games);
@@ -216,6 +247,16 @@ int mz_env_cartpole_reset(void* stream, int32_t num_games, double* state, int32_
     cartpole_reset_kernel<<<env_grid(num_games), kEnvThreads, 0, static_cast<hipStream_t>(stream)>>>(
         num_games, state, steps, ended, initial_state);
     return env_launch_status("mz_env_cartpole_reset");
+}
+
+int mz_env_cartpole_reset_where(void* stream, int32_t num_games, double* state, int32_t* steps, int32_t* ended,
+                                const double* initial_state, const int32_t* where) {
+    MZ_REQUIRE(num_games >= 0, "num_games must be >= 0 (got %d)", num_games);
+    if (num_games == 0) return MZ_OK;
+    MZ_REQUIRE(state && steps && ended && initial_state && where, "state/steps/ended/initial_state/where is NULL");
+    cartpole_reset_where_kernel<<<env_grid(num_games), kEnvThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        num_games, state, steps, ended, initial_state, where);
+    return env_launch_status("mz_env_cartpole_reset_where");
 }
 
 int mz_env_cartpole_observe(void* stream, int32_t num_games, const double* state, const int32_t* ended,

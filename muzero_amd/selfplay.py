@@ -219,6 +219,13 @@ class BatchedHistory:
         self.lengths = z((self.G,), torch.int32)
         self.metadata = {}
 
+    def as_struct(self):
+        """mz_history_t over this history's tensors (keep `self` alive while the struct is in use)."""
+        obs = self.observations.shape[2]
+        return _lib.History(self.G, self.M, obs, self.A, self.observations.data_ptr(), self.to_plays.data_ptr(),
+                            self.actions.data_ptr(), self.rewards.data_ptr(), self.root_values.data_ptr(),
+                            self.policies.data_ptr(), self.lengths.data_ptr())
+
     def to_game_histories(self):
         """-> list of G `game.GameHistory` with the reference's fields (host copies; synchronises)."""
         from .game import GameHistory
@@ -300,13 +307,17 @@ class SelfPlayEngine:
                                 device=self.device)
         self.slot = torch.arange(self.A, device=self.device, dtype=torch.int32).unsqueeze(0)
         self.temperature = torch.empty(self.G, dtype=torch.float64, device=self.device)
+        self._noise = torch.empty(self.G, self.A, dtype=torch.float64, device=self.device)
 
-    def _dirichlet(self, n_legal):
-        """noise[g, :n_legal[g]] ~ Dirichlet(alpha) (agent.py:172), zeros elsewhere: normalised Gamma(alpha, 1) draws."""
-        gamma = torch._standard_gamma(self.alpha, generator=self.generator)
-        gamma = torch.where(self.slot < n_legal.unsqueeze(1), gamma, torch.zeros_like(gamma))
-        total = gamma.sum(dim=1, keepdim=True)
-        return torch.where(total > 0, gamma / total, torch.zeros_like(gamma)).contiguous()
+    def _dirichlet(self, n_legal, gamma=None):
+        """noise[g, :n_legal[g]] ~ Dirichlet(alpha) (agent.py:172), zeros elsewhere: normalised Gamma(alpha, 1) draws
+        (`gamma`: draws made ahead of time, else drawn here)."""
+        if gamma is None:
+            gamma = torch._standard_gamma(self.alpha, generator=self.generator)
+        _lib.check(_lib.load().mz_dirichlet_from_gamma(
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.G, self.A, gamma.data_ptr(),
+            n_legal.data_ptr(), self._noise.data_ptr()))
+        return self._noise
 
     def play_games(self, max_moves: Optional[int] = None, check_every: int = 1) -> BatchedHistory:
         env, cfg = self.env, self.config
@@ -341,9 +352,74 @@ class SelfPlayEngine:
         hist.observations[played].copy_(obs)
         hist.to_plays[played].copy_(env.to_play)
         hist.lengths.copy_(env.steps)
-        env.check_illegal()
+        self._check_devices()
         hist.metadata = {'network_id': str(steps), 'moves_played': played}
         return hist
+
+    def _check_devices(self):
+        """The device-side validation flags, read once per batch: an illegal action handed to the environment
+        (games/tictactoe.py:122-123 raises) or a malformed legal-action list handed to the search."""
+        self.env.check_illegal()
+        for lane in getattr(self.search, 'lanes', [self.search]):
+            lane.pool.counters()                     # raises MuZeroHipError when the pool's err_flag is set
+
+    def play_continuous(self, num_games: int, max_moves: Optional[int] = None, check_every: int = 8) -> BatchedHistory:
+        """The reference agent's outer loop (agent_services.py:47-54: play a game, hand its history over, start the next
+        one at once) for G slots: a slot whose game ends is flushed to the finished store and restarted before the next
+        search, so every move searches a full batch of live games.  Returns the first `num_games` games started (in
+        start order: slot order within a wave of restarts) as one BatchedHistory; games still in flight at the end are
+        dropped.  Slots are at different moves of their games, so the temperature is per slot (config.py:153-157)."""
+        env, cfg, dev, G = self.env, self.config, self.device, self.G
+        lib = _lib.load()
+        M = int(max_moves if max_moves is not None else cfg.mcts_config.max_moves)
+        live = BatchedHistory(M, G, self.network.OBSERVATION_SHAPE, self.A, dev)
+        done = BatchedHistory(M, int(num_games), self.network.OBSERVATION_SHAPE, self.A, dev)
+        live_s, done_s = live.as_struct(), done.as_struct()
+        if self.models_path and self.network.load_latest(self.models_path) and isinstance(self.search, PipelinedSearch):
+            for replica in self.search.networks[1:]:
+                replica.set_weights(self.network.get_weights(), self.network.training_steps())
+        steps_trained = self.network.training_steps()
+        i32 = dict(dtype=torch.int32, device=dev)
+        serial = torch.arange(G, **i32)
+        counters = torch.tensor([G, 0], dtype=torch.int64, device=dev)       # next serial, games stored
+        flush_dst, reset_mask = torch.empty(G, **i32), torch.empty(G, **i32)
+        t_cfg = float(cfg.mcts_config.temperature)
+        for lane in getattr(self.search, 'lanes', [self.search]):
+            lane.pool.set_temperature(t_cfg)
+        freezing = int(cfg.mcts_config.freezing_moves)
+        t_on = torch.full((G,), t_cfg, dtype=torch.float64, device=dev)
+        t_off = torch.zeros(G, dtype=torch.float64, device=dev)
+        stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        env.reset()
+        moves = 0
+        while True:
+            obs, legal, n_legal = env.observe()
+            _lib.check(lib.mz_history_record_observation(stream(), ctypes.byref(live_s), env.steps.data_ptr(),
+                                                         obs.data_ptr(), env.to_play.data_ptr()))
+            # finished games -> the store, their slots restarted (first iteration: nothing is over yet)
+            _lib.check(lib.mz_history_flush(stream(), ctypes.byref(live_s), ctypes.byref(done_s), env.steps.data_ptr(),
+                                            env.ended.data_ptr(), serial.data_ptr(), counters.data_ptr(),
+                                            flush_dst.data_ptr(), reset_mask.data_ptr()))
+            if moves % check_every == 0 and int(counters[1].item()) >= num_games:      # synchronises
+                break
+            env.reset_where(reset_mask)
+            obs, legal, n_legal = env.observe()
+            _lib.check(lib.mz_history_record_observation(stream(), ctypes.byref(live_s), env.steps.data_ptr(),
+                                                         obs.data_ptr(), env.to_play.data_ptr()))
+            noise = self._dirichlet(n_legal)
+            u = torch.rand(G, dtype=torch.float64, device=dev, generator=self.generator)
+            torch.where(env.steps < freezing, t_on, t_off, out=self.temperature)
+            _visits, root_value, _minmax, policy, action = self.search.run(obs, noise, u, self.temperature, legal,
+                                                                           n_legal)
+            reward = env.step(action)
+            _lib.check(lib.mz_history_record_move(stream(), ctypes.byref(live_s), env.steps.data_ptr(),
+                                                  env.status.data_ptr(), action.data_ptr(), reward.data_ptr(),
+                                                  root_value.data_ptr(), policy.data_ptr()))
+            moves += 1
+        self._check_devices()
+        done.metadata = {'network_id': str(steps_trained), 'moves_played': moves, 'slots': G,
+                         'games_started': int(counters[0].item())}
+        return done
 
 
 class TrajectoryGather:

@@ -49,6 +49,10 @@ class VectorEnvironment:
     def reset(self) -> None:
         raise NotImplementedError
 
+    def reset_where(self, where: torch.Tensor) -> None:
+        """Restarts the games with where[g] != 0 (int32 [G]); the others are left as they are."""
+        raise NotImplementedError
+
     def observe(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """-> (observation [G, obs] f32, legal [G, A] i32, n_legal [G] i32); the tensors are reused by the next call."""
         raise NotImplementedError
@@ -92,6 +96,12 @@ class TicTacToeVectorEnv(VectorEnvironment):
                                                   self.to_play.data_ptr(), self.steps.data_ptr(),
                                                   self.ended.data_ptr()))
 
+    def reset_where(self, where):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mz_env_ttt_reset_where(_stream_ptr(self.device), self.G, self.board.data_ptr(),
+                                                        self.to_play.data_ptr(), self.steps.data_ptr(),
+                                                        self.ended.data_ptr(), self._action_ptr(where)))
+
     def observe(self):
         with torch.cuda.device(self.device):
             _lib.check(self._lib.mz_env_ttt_observe(_stream_ptr(self.device), self.G, self.board.data_ptr(),
@@ -134,6 +144,17 @@ class CartPoleVectorEnv(VectorEnvironment):
         with torch.cuda.device(self.device):
             _lib.check(self._lib.mz_env_cartpole_reset(_stream_ptr(self.device), self.G, self.state.data_ptr(),
                                                        self.steps.data_ptr(), self.ended.data_ptr(), init.data_ptr()))
+        self._init_keepalive = init
+
+    def reset_where(self, where, initial_state: Optional[torch.Tensor] = None):
+        if initial_state is None:
+            initial_state = (torch.rand(self.G, 4, dtype=torch.float64, device=self.device,
+                                        generator=self.generator) - 0.5) * 0.1
+        init = initial_state.to(device=self.device, dtype=torch.float64).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mz_env_cartpole_reset_where(_stream_ptr(self.device), self.G, self.state.data_ptr(),
+                                                             self.steps.data_ptr(), self.ended.data_ptr(),
+                                                             init.data_ptr(), self._action_ptr(where)))
         self._init_keepalive = init
 
     def observe(self):

@@ -136,6 +136,70 @@ def test_selfplay_engine_plays_legal_complete_tictactoe_games(lanes):
     assert not torch.equal(again.actions, hist.actions)
 
 
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_selfplay_engine_refills_finished_slots(lanes):
+    """play_continuous: a slot whose game ends is flushed and restarted before the next search (the reference agent's
+    loop, agent_services.py:47-54).  Every stored game -- including the refilled ones -- replays on the host environment
+    to the same observations, players, rewards and length; the store holds exactly the first `num_games` games started."""
+    import torch
+    from muzero_amd.environment import TicTacToeEnvironment
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import SelfPlayEngine
+    G, N, total = 48, 5, 200
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=3)
+    engine = SelfPlayEngine(config, net, G, seed=23, lanes=lanes)
+    hist = engine.play_continuous(total, check_every=3)
+    assert hist.G == total and hist.metadata['slots'] == G and hist.metadata['games_started'] >= total
+    games = hist.to_game_histories()
+    lengths = hist.lengths.cpu().numpy()
+    assert lengths.min() >= 5 and lengths.max() <= 9 and len(set(lengths.tolist())) > 1
+    # more than four waves of games went through the 48 slots, and every move searched a full batch:
+    # moves played x slots >= the moves of the stored games
+    assert hist.metadata['moves_played'] * G >= int(lengths.sum()) and total > 4 * G
+    for g, h in enumerate(games):
+        env = TicTacToeEnvironment()
+        state = env.reset()
+        assert len(h) == lengths[g] and len(h.observations) == len(h) + 1 == len(h.to_plays)
+        done = False
+        for m, a in enumerate(h.actions):
+            np.testing.assert_array_equal(h.observations[m], state.observation)
+            assert h.to_plays[m] == state.to_play and a in state.legal_actions
+            pol = h.policies[m]
+            assert abs(float(pol.sum()) - 1.0) < 1e-6
+            assert (pol[[x for x in range(9) if x not in state.legal_actions]] == 0).all()
+            assert -1.0 <= h.root_values[m] <= 1.0
+            state, r, done, _ = env.step(a)
+            assert h.rewards[m] == r
+        assert done
+        np.testing.assert_array_equal(h.observations[-1], state.observation)
+        assert h.to_plays[-1] == state.to_play
+    # same seed, same games; the first G games are the ones a plain batch would start with
+    again = SelfPlayEngine(config, net, G, seed=23, lanes=lanes).play_continuous(total, check_every=5)
+    for f in hist.FIELDS:
+        assert torch.equal(getattr(hist, f), getattr(again, f)), f
+
+
+def test_selfplay_engine_refills_cartpole_with_a_move_cap():
+    """Slots that reach the move capacity without the episode ending are flushed as truncated games (agent.py:34's
+    `len(history) < max_moves`) and restarted like finished ones."""
+    from muzero_amd.games import cartpole
+    from muzero_amd.selfplay import SelfPlayEngine
+    G, N, M, total = 32, 4, 10, 100
+    config = cartpole.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=1)
+    hist = SelfPlayEngine(config, net, G, seed=2).play_continuous(total, max_moves=M, check_every=4)
+    lengths = hist.lengths.cpu().numpy()
+    assert hist.G == total and (lengths >= 1).all() and (lengths <= M).all()
+    rew, acts = hist.rewards.cpu().numpy(), hist.actions.cpu().numpy()
+    obs = hist.observations.cpu().numpy()
+    for g in range(total):
+        assert set(acts[:lengths[g], g].tolist()) <= {0, 1}
+        assert (rew[:lengths[g], g] == 1.0).all() and (rew[lengths[g]:, g] == 0.0).all()
+        assert (np.abs(obs[0, g]) <= 0.05).all()                 # every game starts from a fresh reset state
+    np.testing.assert_allclose(hist.policies.cpu().numpy()[0].sum(-1), 1.0, atol=1e-6)
+
+
 def test_selfplay_engine_cartpole_short_episodes():
     import torch
     from muzero_amd.games import cartpole

@@ -25,3 +25,28 @@ for name, mod, G, N, max_moves in (('tictactoe', tictactoe, 4096, 25, None), ('c
         assert (lengths >= 1).all()
         print(f'{name}: batch {b}: {G} games, {moves} moves, {moves * N / dt / 1e6:.1f} M simulations/s end to end, '
               f'{G / dt:.0f} games/s, lengths {lengths.min()}..{lengths.max()}', flush=True)
+    # the per-move rate of the search alone on this box (what bench.py measures), for the ratio below
+    engine.env.reset()
+    obs, legal, n_legal = engine.env.observe()
+    noise = engine._dirichlet(n_legal)
+    u = torch.rand(G, dtype=torch.float64, device=engine.device)
+    temp = torch.ones(G, dtype=torch.float64, device=engine.device)
+    for _ in range(3):
+        engine.search.run(obs, noise, u, temp, legal, n_legal)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        engine.search.run(obs, noise, u, temp, legal, n_legal)
+    torch.cuda.synchronize(); per_move = 20 * G * N / (time.perf_counter() - t0)
+    print(f'{name}: search alone: {per_move / 1e6:.1f} M simulations/s per move', flush=True)
+    # continuous refill: finished slots restart at once, every move searches a full batch (agent_services.py:47-54)
+    total = 4 * G
+    for b in range(batches):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        hist = engine.play_continuous(total, max_moves=max_moves, check_every=8)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        searched = hist.metadata['moves_played'] * G * N
+        stored = int(hist.lengths.sum().item())
+        print(f'{name}: refill {b}: {total} games stored ({hist.metadata["games_started"]} started) in '
+              f'{hist.metadata["moves_played"]} moves, {searched / dt / 1e6:.1f} M simulations/s searched, '
+              f'{stored * N / dt / 1e6:.1f} M simulations/s in stored games, {total / dt:.0f} games/s; end to end = '
+              f'{searched / dt / per_move:.3f} of the per-move rate', flush=True)
