@@ -183,12 +183,24 @@ int32_t mz_net_num_actions(int32_t kind);
 int32_t mz_net_observation_size(int32_t kind);
 
 /* Uploads (and re-lays-out for the kernels) a flat f32 weight buffer in Keras order.
- *   weights_host: HOST pointer, mz_net_num_weights(kind) floats;  training_steps: Network.training_steps(). */
+ *   weights_host: HOST pointer, mz_net_num_weights(kind) floats;  training_steps: Network.training_steps().
+ * Numeric domain.  The kernels multiply on f16 matrix cores with every f32 operand carried as two halfs,
+ * v = h + l/2048 (h = f16(v), l = f16((v - h) * 2048), both rounded toward zero): products and sums are exact to f32
+ * accumulation, results within 1e-5 of an fp64 evaluation (relative to each output tensor's scale) -- provided every
+ * weight and every activation (hidden states, layer outputs, observations fed to a matrix stage) satisfies
+ * |v| <= 65504, f16's largest finite value; below 6.1e-5 a value is carried with absolute precision 2.9e-11 instead of
+ * relative precision 2^-21.  A weight outside the range (or not finite) is rejected here with MZ_ERR_INVALID_ARG; an
+ * activation outside it saturates at 65504 and raises the handle's range flag (mz_net_status).  (CartPole batches above
+ * 8192 run on f32 matrix instructions and have no such limit.) */
 int mz_net_create(int32_t kind, const float* weights_host, int64_t num_weights, int64_t training_steps,
                   void* stream, mz_net_t** out_net);
 int mz_net_destroy(mz_net_t* net);
 int mz_net_set_stream(mz_net_t* net, void* stream);
 int64_t mz_net_training_steps(mz_net_t* net);
+/* Health of the inferences run on this handle since the last call: *out_flags_host (HOST) receives bit 0 = some
+ * activation left the kernels' numeric domain (|v| > 65504, see mz_net_create) and was saturated -- outputs computed
+ * from it are not to the stated tolerance.  Clears the flag.  Synchronises the handle's stream. */
+int mz_net_status(mz_net_t* net, int32_t* out_flags_host);
 /* Measurement hook (no counterpart in the reference): when hip_event (a hipEvent_t) is non-NULL, every later
  * inference call that consists of two launches (TicTacToe: per-cell kernel, then head kernel) records it on the
  * stream between them, so a caller bracketing the call with its own events can time each kernel. NULL disables. */

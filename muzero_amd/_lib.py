@@ -80,6 +80,7 @@ PROTOTYPES = {
     'mz_net_destroy': (ctypes.c_int, [c_void_p]),
     'mz_net_set_stream': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_net_training_steps': (c_int64, [c_void_p]),
+    'mz_net_status': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_net_set_mid_event': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_infer_recurrent_step': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p,

@@ -175,6 +175,7 @@ struct TttDev {
     int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     int job_cells[4][3];        // the cells of job j, -1 = none
     float dyn_reward_b, pred_value_b;
+    int* range_flag;            // raised when a kernel splits a value outside the split-f16 domain (mz_net_status)
 };
 
 // ---- split-f16 MFMA --------------------------------------------------------------------------------------------------
@@ -203,9 +204,13 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
 }
 // The split image of a row of 128 values is [128 h | 128 l] halfs.  Four consecutive values of a row -> their four h and
 // four l halfs, 8 bytes each (two packed conversions and packed f32 arithmetic per pair).
-__device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l) {
+// `vmax` keeps the largest magnitude this lane has split (two v_max3 with |.| source modifiers): a value beyond f16's
+// range saturates in the conversion, which the kernels report through range_flag (note_range) instead of hiding it.
+__device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l, float& vmax) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
+    vmax = fmaxf(fmaxf(vmax, fabsf(v[0])), fabsf(v[1]));
+    vmax = fmaxf(fmaxf(vmax, fabsf(v[2])), fabsf(v[3]));
     unsigned hw[2], lw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -217,6 +222,12 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& l) 
     }
     h = make_uint2(hw[0], hw[1]);
     l = make_uint2(lw[0], lw[1]);
+}
+
+constexpr float kSplitMax = 65504.f;          // f16's largest finite value
+// end of a kernel: raise the network's range flag if this lane split a value outside the split-f16 domain
+__device__ __forceinline__ void note_range(float vmax, int* range_flag) {
+    if (!(vmax <= kSplitMax)) atomicOr(range_flag, 1);
 }
 
 // ---- the TicTacToe job kernel
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
         if (off >= 0) svalid |= 1u << i;
     }
     float4 stg[4];
+    float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
     auto commit = [&](_Float16* buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
             } else {
                 const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
                 uint2 h, l;
-                split4(v, h, l);
+                split4(v, h, l, vmax);
                 *reinterpret_cast<uint2*>(buf + r * kLdW + c4 * 4) = h;
                 *reinterpret_cast<uint2*>(buf + r * kLdW + 128 + c4 * 4) = l;
             }
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
                                         fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
                     uint2 h, l;
-                    split4(v, h, l);
+                    split4(v, h, l, vmax);
                     _Float16* row = sX + (16 * m + n16) * kLdW + lcol;
                     *reinterpret_cast<uint2*>(row) = h;
                     *reinterpret_cast<uint2*>(row + 128) = l;
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     // reward head (games/tictactoe.py:193-195): this lane's four columns
                     rdot[m] = __builtin_fmaf(v[3], rw.w, __builtin_fmaf(v[2], rw.z, __builtin_fmaf(v[1], rw.y, v[0] * rw.x)));
                     uint2 h, l;
-                    split4(v, h, l);
+                    split4(v, h, l, vmax);
                     _Float16* row = sH + (16 * m + n16) * kLdW + lcol;
                     *reinterpret_cast<uint2*>(row) = h;
                     *reinterpret_cast<uint2*>(row + 128) = l;
@@ -531,6 +543,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
         Dn = Dn2;
         Dn2 = Dn3;
     }
+    note_range(vmax, w.range_flag);
 }
 
 // One 128 x 128 GEMM stage on split operands without the job kernel's pipelining: acc += sA[32][128] * W, weights in b
@@ -581,6 +594,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     const int job = ((bi & 3) + ((bi >> 5) & 1) * 2) & 3, rb = (bi >> 2) * 8 + xl;
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
     const int row0 = rb * ROWS;
+    float vmax = 0.f;
     for (int i = tid; i < ROWS * 27; i += kThreads) {
         const int b = row0 + i / 27;
         sObs[i] = b < B ? observation[(size_t)b * 27 + i % 27] : 0.f;
@@ -628,7 +642,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
         for (int i = 0; i < 4; ++i) {
             const float x[4] = {fmaxf(s[i].x, 0.f), fmaxf(s[i].y, 0.f), fmaxf(s[i].z, 0.f), fmaxf(s[i].w, 0.f)};
             uint2 h, l;
-            split4(x, h, l);
+            split4(x, h, l, vmax);
             _Float16* row = sX + (r0 + 8 * i) * kLdH + 4 * c4;
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
             const float x[4] = {fmaxf(acc[4 * q] + db[q].x, 0.f), fmaxf(acc[4 * q + 1] + db[q].y, 0.f),
                                 fmaxf(acc[4 * q + 2] + db[q].z, 0.f), fmaxf(acc[4 * q + 3] + db[q].w, 0.f)};
             uint2 h, l;
-            split4(x, h, l);
+            split4(x, h, l, vmax);
             *reinterpret_cast<uint2*>(sH + lrow * kLdH + lcol + 8 * q) = h;
             *reinterpret_cast<uint2*>(sH + lrow * kLdH + 128 + lcol + 8 * q) = l;
             if (!SPLIT_IO && lrow_ok)
@@ -669,6 +683,7 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
             *reinterpret_cast<float4*>(pjob + (unsigned)lrow * 1152u + lcol + 8 * q) =
                 make_float4(accp[4 * q], accp[4 * q + 1], accp[4 * q + 2], accp[4 * q + 3]);
     }
+    note_range(vmax, w.range_flag);
 }
 
 // Prediction head of 16 games by one 256-thread workgroup: relu(sum of the NP partial products + bias)
@@ -686,6 +701,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
                                            const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12]) {
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
+    float vmax = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g = lane >> 4;
     // biases first: a load issued after the MFMAs would show its whole latency
@@ -741,7 +757,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             }
             const float x[4] = {fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
             uint2 h, l;
-            split4(x, h, l);
+            split4(x, h, l, vmax);
             _Float16* row = sX + ((tid >> 5) + 8 * i) * kLdH + 4 * c4;
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
@@ -781,7 +797,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = fmaxf(acc[c][i] + acx[c][i] * kUnsplit + bb[i], 0.f);
             uint2 h, l;
-            split4(x, h, l);
+            split4(x, h, l, vmax);
             _Float16* row = sH + n16 * kLdH + wave * 32 + 16 * c + 4 * g;
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
@@ -814,6 +830,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             }
         }
     }
+    note_range(vmax, w.range_flag);
     __syncthreads();
 }
 
@@ -908,6 +925,7 @@ struct CartDev {
     const float* pred_dense2_s;
     const float* pred_value_s;
     float dyn_reward_b;
+    int* range_flag;            // see TttDev
 };
 
 // One launch per call; grid = ceil(B / (32*MT)).  Six chained GEMM stages; each stage's weights are loaded into
@@ -1201,9 +1219,10 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
         v[2] = fmaxf(acc[2] + bias.z, 0.f);
         v[3] = fmaxf(acc[3] + bias.w, 0.f);
     };
+    float vmax = 0.f;
     auto store4 = [&](const float (&v)[4], _Float16* sOut) {
         uint2 h, l;
-        split4(v, h, l);
+        split4(v, h, l, vmax);
         *reinterpret_cast<uint2*>(sOut + n16 * kLdW + lcol) = h;
         *reinterpret_cast<uint2*>(sOut + n16 * kLdW + 128 + lcol) = l;
     };
@@ -1234,6 +1253,7 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
                 }
             }
             _Float16 h, l;
+            vmax = fmaxf(vmax, s);
             split_f16(fmaxf(s, 0.f), h, l);
             sX[r * kLdW + nn] = h;
             sX[r * kLdW + 128 + nn] = l;
@@ -1248,7 +1268,7 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
             const float4 x = off >= 0 ? *reinterpret_cast<const float4*>(in_base + off + c4 * 4) : zero4;
             const float xv[4] = {x.x, x.y, x.z, x.w};
             uint2 h, l;
-            split4(xv, h, l);
+            split4(xv, h, l, vmax);
             *reinterpret_cast<uint2*>(sH + r * kLdW + c4 * 4) = h;
             *reinterpret_cast<uint2*>(sH + r * kLdW + 128 + c4 * 4) = l;
         }
@@ -1352,6 +1372,7 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
             sOut[row][2 + q] = logit;
         }
     }
+    note_range(vmax, w.range_flag);
     if (FUSE) {
         __syncthreads();
         if (wave == 0) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
@@ -1422,6 +1443,7 @@ struct AtariDev {
     const float* pred_dense_b;  // [128]
     const float* pred_head_b;   // [32]: value bias, 18 policy biases, zeros
     float dyn_reward_b;
+    int* range_flag;            // see TttDev
 };
 
 // One 128 x 128 stage: acc[m] += sA[rows 16m .. 16m+15][128] * W[128][this wave's 16 columns] (weights as the row operand:
@@ -1477,12 +1499,12 @@ __device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
 }
 
 // v[m] = relu(x[m] + bias) of this lane's four columns; split and stored into rows 16 m + n16 of an LDS tile
-__device__ __forceinline__ void store_tile4(const f32x4 (&v)[4], _Float16* tile, int n16, int lcol) {
+__device__ __forceinline__ void store_tile4(const f32x4 (&v)[4], _Float16* tile, int n16, int lcol, float& vmax) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const float x[4] = {v[m][0], v[m][1], v[m][2], v[m][3]};
         uint2 h, l;
-        split4(x, h, l);
+        split4(x, h, l, vmax);
         _Float16* row = tile + (16 * m + n16) * kLdW + lcol;
         *reinterpret_cast<uint2*>(row) = h;
         *reinterpret_cast<uint2*>(row + 128) = l;
@@ -1511,6 +1533,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
     const float4* wlane = reinterpret_cast<const float4*>(INITIAL ? w.ini_s : w.rec_s) + wave * 64 + lane;
     BFragW bw;
     load_bw(bw, INITIAL ? w.ini_s : w.rec_s, lane, wave);
+    float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
     if (tid < ROWS) {
         const int b = row0 + tid;
         long off = -1;
@@ -1542,7 +1565,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
             const int idx = tid + kThreadsW * i, r = idx >> 6, c4 = idx & 63;
             const float x[4] = {in[i].x, in[i].y, in[i].z, in[i].w};
             uint2 h, l;
-            split4(x, h, l);
+            split4(x, h, l, vmax);
             _Float16* row = sT[c4 >> 5] + r * kLdW + (c4 & 31) * 4;
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
@@ -1595,7 +1618,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
 #pragma unroll
                 for (int m = 0; m < 4; ++m) res[p][m] = v[m];
             }
-            store_tile4(v, dst[p], n16, lcol);
+            store_tile4(v, dst[p], n16, lcol, vmax);
         }
         __syncthreads();
     }
@@ -1614,7 +1637,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
             stage += 1;
 #pragma unroll
             for (int m = 0; m < 4; ++m) res[p][m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
-            store_tile4(res[p], sT[p], n16, lcol);
+            store_tile4(res[p], sT[p], n16, lcol, vmax);
         }
         __syncthreads();
     }
@@ -1653,7 +1676,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         f32x4 v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bp, f32x4{0.f, 0.f, 0.f, 0.f});
-        store_tile4(v, tP, n16, lcol);
+        store_tile4(v, tP, n16, lcol, vmax);
     }
     __syncthreads();
     if (!INITIAL && tid < ROWS) {                    // reward = tanh(<hidden', w> + b)
@@ -1671,7 +1694,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         f32x4 v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
-        store_tile4(v, tD, n16, lcol);
+        store_tile4(v, tD, n16, lcol, vmax);
     }
     __syncthreads();
     if (wave < 2) {                                  // heads: column 0 = value (tanh), 1 .. 18 = policy logits
@@ -1698,6 +1721,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         if (out_value_raw) out_value_raw[row0 + tid] = sOut[tid][0];
         if (!INITIAL) out_reward[row0 + tid] = sOut[tid][19];
     }
+    note_range(vmax, w.range_flag);
 }
 
 struct Packer {
@@ -1773,6 +1797,7 @@ struct mz_net {
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
     float* rpart = nullptr;        //                    [cap][9] reward partials
     int scratch_cap = 0;
+    int* range_flag = nullptr;     // device word raised by the kernels when a value leaves the split-f16 domain
     float* static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array (mz_infer_recurrent_noalloc)
     bool hidden_split = false;        // inside a native move: the hidden workspace holds split images (mz_net_begin_move)
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
@@ -2089,6 +2114,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         put(c.pred_value_s, pk.add_split16(pred_value, 101, 101));
         c.dyn_reward_b = dyn_reward_b[0];
     }
+    const size_t range_off = pk.add(std::vector<float>(4, 0.f));       // the range flag (an int) lives with the tables
     hipError_t e = hipGetDevice(&net->device);
     if (e == hipSuccess) {
         const int st = scratch_for_device(net->device, &net->static_scratch);      // once per device, that device current
@@ -2105,6 +2131,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
     for (auto& f : fix) *f.first = net->weights + f.second;
+    net->range_flag = reinterpret_cast<int*>(net->weights + range_off);
+    net->ttt.range_flag = net->cart.range_flag = net->atari.range_flag = net->range_flag;
     *out_net = net;
     return MZ_OK;
 }
@@ -2133,6 +2161,17 @@ int mz_net_set_stream(mz_net_t* net, void* stream) {
 }
 
 int64_t mz_net_training_steps(mz_net_t* net) { return net ? net->training_steps : -1; }
+
+int mz_net_status(mz_net_t* net, int32_t* out_flags_host) {
+    MZ_REQUIRE(net != nullptr && out_flags_host != nullptr, "net/out_flags_host is NULL");
+    MZ_HIP(hipSetDevice(net->device));
+    int flags = 0;
+    MZ_HIP(hipMemcpyAsync(&flags, net->range_flag, sizeof(int), hipMemcpyDeviceToHost, net->stream));
+    MZ_HIP(hipMemsetAsync(net->range_flag, 0, sizeof(int), net->stream));
+    MZ_HIP(hipStreamSynchronize(net->stream));
+    *out_flags_host = flags;
+    return MZ_OK;
+}
 
 #ifdef MZ_TREE_TRACE
 // experiment builds only: the per-wavefront phase counters of THIS translation unit (the job kernel's stamps)

@@ -212,6 +212,21 @@ class Network:
             self.set_weights(data['weights'], int(data['steps']))
         return True
 
+    def status(self) -> int:
+        """mz_net_status: bit 0 = an activation left the kernels' numeric domain (|v| > 65504) since the last call and was
+        saturated.  Clears the flag; synchronises."""
+        self._sync_stream()
+        flags = ctypes.c_int32(0)
+        _lib.check(self._lib.mz_net_status(self._h, ctypes.addressof(flags)))
+        return int(flags.value)
+
+    def check_range(self) -> None:
+        """Raises MuZeroError if an inference since the last check saturated an activation (see include/mzhip.h,
+        mz_net_create: the numeric domain of the split-f16 kernels)."""
+        if self.status() & 1:
+            raise MuZeroError(f'{type(self).__name__}: an activation exceeded the inference kernels\' numeric domain '
+                              '(|v| > 65504) and was saturated; outputs since the last check are unreliable')
+
     def close(self):
         if self._h is not None:
             self._lib.mz_net_destroy(self._h)

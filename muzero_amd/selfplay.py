@@ -362,6 +362,8 @@ class SelfPlayEngine:
         self.env.check_illegal()
         for lane in getattr(self.search, 'lanes', [self.search]):
             lane.pool.counters()                     # raises MuZeroHipError when the pool's err_flag is set
+            if isinstance(lane.network, Network):
+                lane.network.check_range()           # an activation outside the kernels' numeric domain
 
     def play_continuous(self, num_games: int, max_moves: Optional[int] = None, check_every: int = 8) -> BatchedHistory:
         """The reference agent's outer loop (agent_services.py:47-54: play a game, hand its history over, start the next

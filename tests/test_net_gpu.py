@@ -72,6 +72,83 @@ def test_initial_and_recurrent_inference(kind, B):
     assert outs[B - 1].value == float(out2.batch_value_scalar[B - 1])
 
 
+def _scaled_close(got, want, what):
+    """1e-5 relative to the tensor's scale: rtol 1e-5 plus atol 1e-5 x max|want|."""
+    want = np.asarray(want)
+    np.testing.assert_allclose(got.detach().cpu().numpy().reshape(want.shape), want, rtol=RTOL,
+                               atol=ATOL * max(float(np.abs(want).max()), 1e-30), err_msg=what)
+
+
+@pytest.mark.parametrize('scale', [8.0, 1.0 / 64.0])
+@pytest.mark.parametrize('kind', ['tictactoe', 'cartpole', 'atari'])
+def test_split_f16_numeric_domain(kind, scale):
+    """The kernels carry every f32 operand as two f16 halfs (include/mzhip.h, mz_net_create: |v| <= 65504).  With every
+    weight scaled by 8 the activations grow ~64x per layer pair, with 1/64 they shrink towards f16's subnormals: inside
+    the domain the outputs stay within 1e-5 of the fp64 oracle relative to each tensor's scale and the range flag stays
+    down; once an activation leaves the domain the handle says so (mz_net_status) instead of returning clamped numbers
+    silently."""
+    from muzero_amd.network import AtariShapedNetwork, CartPoleNetwork, TicTacToeNetwork
+    cls = {'tictactoe': TicTacToeNetwork, 'cartpole': CartPoleNetwork, 'atari': AtariShapedNetwork}[kind]
+    flat = (no.random_weights(kind, 23) * np.float32(scale)).astype(np.float32)
+    net, ref = cls(config=None, weights=flat), no.make_oracle(kind, flat)
+    rng = np.random.default_rng(4)
+    B = 150
+    obs = observations(kind, B, rng)
+    out = net.initial_inference(obs)
+    h, v, logits, raw = ref.initial_inference(obs)
+    if not (kind == 'cartpole' and scale > 1):
+        # (CartPole's two-hot preprocessing runs in f32 like the reference's TF graph, utils.py:138-143: the bin weights
+        # carry ~1e-5 of absolute error, which the x8 layers amplify 64-fold -- not a property of the split arithmetic)
+        _scaled_close(out.batch_hidden_state, h, 'initial hidden')
+        _scaled_close(out.batch_policy_logits, logits, 'initial logits')
+        _scaled_close(out.batch_value_scalar, v, 'initial value')
+    assert net.status() == 0
+    saturated = False
+    hidden_in = h.astype(np.float32)                     # the recurrent steps start from the oracle's hidden state
+    h = hidden_in.astype(np.float64)
+    for step in range(3):
+        action = rng.integers(0, ref.A, size=B)
+        out = net.recurrent_inference(hidden_in, action)
+        h, r, v, logits, _ = ref.recurrent_inference(h, action)
+        flags = net.status()
+        hmax = float(np.abs(h).max())
+        if hmax > 2.0e5:                                  # clearly outside: the flag must be up
+            assert flags & 1, f'step {step}: activations up to {hmax:.3g} went unreported'
+        if flags & 1:
+            # raised by some layer's output (the conv feeding the dense is ~8x the hidden state it produces): never
+            # inside a comfortably small network
+            assert scale > 1 and hmax > 1.0e3, f'step {step}: range flag raised with max |hidden| = {hmax:.3g}'
+            saturated = True
+            break
+        _scaled_close(out.batch_hidden_state, h, f'hidden, step {step}')
+        _scaled_close(out.batch_reward_scalar, r, f'reward, step {step}')
+        _scaled_close(out.batch_policy_logits, logits, f'logits, step {step}')
+        _scaled_close(out.batch_value_scalar, v, f'value, step {step}')
+        hidden_in = out.batch_hidden_state.cpu().numpy().reshape(h.shape)              # continue from the kernel's state
+        h = hidden_in.astype(np.float64)
+    if scale > 1 and kind != 'cartpole':
+        assert saturated, 'the x8 network was expected to leave the domain within three unrolled steps'
+    with pytest.raises(Exception):
+        net2 = cls(config=None, weights=flat)
+        big = np.full((B, ref.H), 1.0e6, np.float32)
+        net2.recurrent_inference(big, rng.integers(0, ref.A, size=B))
+        net2.check_range()
+
+
+def test_weights_outside_the_domain_are_rejected():
+    from muzero_amd.exceptions import MuZeroError
+    from muzero_amd.network import TicTacToeNetwork
+    flat = no.random_weights('tictactoe', 1)
+    for bad in (np.inf, np.nan, 7.0e4, -1.0e5):
+        w = flat.copy()
+        w[12345] = bad
+        with pytest.raises(MuZeroError):
+            TicTacToeNetwork(config=None, weights=w)
+    w = flat.copy()
+    w[12345] = 6.0e4                                        # inside the range
+    TicTacToeNetwork(config=None, weights=w)
+
+
 def test_cartpole_large_batch_takes_the_row_tile_kernel():
     """Batches up to 8192 games run 16 per workgroup (cartpole16_kernel); beyond that the 32/64-row tiles do."""
     net, ref = make('cartpole')
