@@ -347,8 +347,8 @@ def cpu_baseline(wl, seconds, cores=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='tictactoe_4096x25', choices=sorted(WORKLOADS))
     ap.add_argument('--trees', type=int, default=None, help='override trees per GPU (profiling only)')
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
@@ -390,10 +390,13 @@ def main():
     move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride) if with_net
             else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
 
-    for _ in range(args.warmup):
-        move.run()
+    for i in range(args.warmup):
+        move.run(timed_events=(i == 0))              # the first warm-up step also warms the event-recording path
     if with_net:
         move.finish()
+        move.hooks.sets.clear()                      # warm-up timings are not reported
+    else:
+        move.event_sets.clear()
     torch.cuda.synchronize()
     c0 = move.counters()
     if world > 1:
