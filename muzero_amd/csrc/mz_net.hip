@@ -1447,29 +1447,33 @@ struct AtariDev {
 };
 
 // One 128 x 128 stage: acc[m] += sA[rows 16m .. 16m+15][128] * W[128][this wave's 16 columns] (weights as the row operand:
-// acc[m][i] = column 4 (lane / 16) + i of the wave's 16, row 16 m + lane % 16).  bw holds this stage's fragments and is
-// re-loaded in place with the next stage's (wnext, this lane's slice) as the k-steps retire.
-template <bool LOAD_NEXT>
-__device__ __forceinline__ void stage64(const _Float16* sA, BFragW& bw, const float4* __restrict__ wnext, f32x4 (&acc)[4],
-                                        int n16, int g) {
+// acc[m][i] = column 4 (lane / 16) + i of the wave's 16, row 16 m + lane % 16); acx[m] collects the two cross terms
+// (bl*ah + bh*al), which the caller folds in once per accumulation: acc += acx / 2048.  bw holds this stage's fragments
+// and is re-loaded in place with the next stage's (wnext, this lane's slice) as the k-steps retire.  The activation
+// fragments run through a two-deep ring `af` that CONTINUES across stages: PRIMED says the caller's previous stage already
+// requested this stage's first k-step, and next_sA (a tile that is complete NOW -- not one this layer is still writing) is
+// the tile whose first k-step this stage requests under its last MFMAs, so that a stage never starts by waiting for LDS.
+template <bool LOAD_NEXT, bool PRIMED>
+__device__ __forceinline__ void stage64(const _Float16* sA, const _Float16* next_sA, BFragW& bw,
+                                        const float4* __restrict__ wnext, f32x4 (&acc)[4], f32x4 (&acx)[4],
+                                        float4 (&af)[2][4][2], int n16, int g) {
     const _Float16* ap = sA + n16 * kLdW + 8 * g;
-    f32x4 acx[4];
+    if (!PRIMED) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 af[2][4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
-        af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+        for (int m = 0; m < 4; ++m) {
+            af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+            af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the priming reads come first
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the priming reads come first
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (s + 1 < 4) {
+        const _Float16* np = s + 1 < 4 ? ap + 32 * (s + 1) : next_sA != nullptr ? next_sA + n16 * kLdW + 8 * g : nullptr;
+        if (s + 1 < 4 || next_sA != nullptr) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
-                af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+                af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW);
+                af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
             }
         }
         const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
@@ -1485,10 +1489,14 @@ __device__ __forceinline__ void stage64(const _Float16* sA, BFragW& bw, const fl
             bw.v[2 * s + 1] = wnext[(2 * s + 1) * 512];
         }
         // pin the interleave: the next k-step's eight fragment reads, this k-step's twelve MFMAs, its VMEM reads
-        if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        if (s + 1 < 4 || next_sA != nullptr) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         if (LOAD_NEXT) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     }
+}
+
+// acc += acx / 2048: the cross terms of a finished accumulation
+__device__ __forceinline__ void fold4(f32x4 (&acc)[4], const f32x4 (&acx)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
 }
@@ -1571,6 +1579,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
             *reinterpret_cast<uint2*>(row + 128) = l;
         }
     }
+    MZ_TRACE_DECL;
     const unsigned long long rowmask = __ballot(sRowOff[lane] >= 0);     // rows with an output; this lane's: n16 + 16 m
     // the residual stream x[position][row block]: first the input conv's per-row bias (conv bias + action planes, the
     // one-hot encoder's planes being constant per position: network.py:14-40), then the layer outputs
@@ -1584,9 +1593,12 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
             res[p][m] = f32x4{bq.x, bq.y, bq.z, bq.w};
         }
     __syncthreads();
+    MZ_TRACE_NW(0);                                  // prologue: gather, split, barrier
 
     int stage = 0;                                   // index of the matrix bw holds; the ring loads stage + 1
-    f32x4 acc[4];
+    f32x4 acc[4], acx[4];
+    float4 af[2][4][2];                              // the activation-fragment ring (stage64)
+    constexpr int kSF = kAtariStageFloats / 4;       // float4 per stage matrix
     constexpr int NL = INITIAL ? 1 : 5;
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) {
@@ -1599,9 +1611,15 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             zero4(acc);
-            stage64<true>(src0, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
-            stage64<true>(src1, bw, wlane + (size_t)(stage + 2) * (kAtariStageFloats / 4), acc, n16, g);
+            zero4(acx);
+            // the first stage of a layer starts cold (its tile was being written until the barrier); every later stage
+            // of the layer finds its first fragments requested by the one before
+            if (p == 0) stage64<true, false>(src0, src1, bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
+            else stage64<true, true>(src0, src1, bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
+            stage64<true, true>(src1, p == 0 ? src0 : nullptr, bw, wlane + (size_t)(stage + 2) * kSF, acc, acx, af, n16, g);
             stage += 2;
+            fold4(acc, acx);
+            MZ_TRACE_NW(1);                          // two stages
             f32x4 v[4];
             if (l == 0) {                            // input conv: + bias (+ action planes), relu = x
 #pragma unroll
@@ -1619,8 +1637,10 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
                 for (int m = 0; m < 4; ++m) res[p][m] = v[m];
             }
             store_tile4(v, dst[p], n16, lcol, vmax);
+            MZ_TRACE_NW(2);                          // epilogue
         }
         __syncthreads();
+        MZ_TRACE_NW(3);                              // barrier
     }
     const _Float16* fin0 = INITIAL ? sT[0] : sT[2];      // the tiles holding the hidden state the prediction reads
     const _Float16* fin1 = INITIAL ? sT[1] : sT[3];
@@ -1633,8 +1653,11 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             zero4(acc);
-            stage64<true>(sT[2 + p], bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+            zero4(acx);
+            if (p == 0) stage64<true, false>(sT[2], sT[3], bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
+            else stage64<true, true>(sT[3], nullptr, bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
             stage += 1;
+            fold4(acc, acx);
 #pragma unroll
             for (int m = 0; m < 4; ++m) res[p][m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
             store_tile4(res[p], sT[p], n16, lcol, vmax);
@@ -1665,14 +1688,17 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
             }
         }
     }
+    MZ_TRACE_NW(4);                                  // hidden state out, reward partials
     // prediction: Conv1D k=2 valid over the two positions, relu -> P
     {
         const float4 bq = *reinterpret_cast<const float4*>(w.pred_conv_b + lcol);
         const f32x4 bp = {bq.x, bq.y, bq.z, bq.w};
         zero4(acc);
-        stage64<true>(fin0, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
-        stage64<true>(fin1, bw, wlane + (size_t)(stage + 2) * (kAtariStageFloats / 4), acc, n16, g);
+        zero4(acx);
+        stage64<true, false>(fin0, fin1, bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
+        stage64<true, true>(fin1, nullptr, bw, wlane + (size_t)(stage + 2) * kSF, acc, acx, af, n16, g);
         stage += 2;
+        fold4(acc, acx);
         f32x4 v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bp, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -1689,18 +1715,23 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         const float4 bq = *reinterpret_cast<const float4*>(w.pred_dense_b + lcol);
         const f32x4 bd = {bq.x, bq.y, bq.z, bq.w};
         zero4(acc);
-        stage64<true>(tP, bw, wlane + (size_t)(stage + 1) * (kAtariStageFloats / 4), acc, n16, g);
+        zero4(acx);
+        stage64<true, false>(tP, nullptr, bw, wlane + (size_t)(stage + 1) * kSF, acc, acx, af, n16, g);
         stage += 1;
+        fold4(acc, acx);
         f32x4 v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = __builtin_elementwise_max(acc[m] + bd, f32x4{0.f, 0.f, 0.f, 0.f});
         store_tile4(v, tD, n16, lcol, vmax);
     }
     __syncthreads();
+    MZ_TRACE_NW(5);                                  // prediction conv + dense (3 stages, 2 barriers)
     if (wave < 2) {                                  // heads: column 0 = value (tanh), 1 .. 18 = policy logits
         const float4 bq = *reinterpret_cast<const float4*>(w.pred_head_b + lcol);
         zero4(acc);
-        stage64<false>(tD, bw, wlane, acc, n16, g);
+        zero4(acx);
+        stage64<false, false>(tD, nullptr, bw, wlane, acc, acx, af, n16, g);
+        fold4(acc, acx);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const float x[4] = {acc[m][0] + bq.x, acc[m][1] + bq.y, acc[m][2] + bq.z, acc[m][3] + bq.w};
@@ -1722,6 +1753,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         if (!INITIAL) out_reward[row0 + tid] = sOut[tid][19];
     }
     note_range(vmax, w.range_flag);
+    MZ_TRACE_NW(6);                                  // heads, outputs
 }
 
 struct Packer {

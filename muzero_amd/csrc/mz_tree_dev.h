@@ -92,8 +92,8 @@ __device__ __forceinline__ double dpp_f64(double x) {
 }
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
-__device__ __forceinline__ double max_f64(double a, double b) { return b > a ? b : a; }   // operands are never NaN
-__device__ __forceinline__ double min_f64(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ double max_f64(double a, double b) { return __builtin_fmax(a, b); }   // operands are never NaN:
+__device__ __forceinline__ double min_f64(double a, double b) { return __builtin_fmin(a, b); }   // one v_max_f64 / v_min_f64
 __device__ __forceinline__ int max_i32(int a, int b) { return b > a ? b : a; }
 
 template <int G, bool MAX>
