@@ -237,7 +237,7 @@ class NetworkMove:
             cells = torch.randint(0, 3, (T, 9), generator=g, device=device)
             to_play = torch.randint(0, 2, (T, 1), generator=g, device=device).expand(T, 9)
             self.obs = torch.stack([(cells == 0), (cells == 1), to_play.bool()], -1).float().reshape(T, 27).contiguous()
-            self.dominant = 'ttt_job_kernel'
+            self.dominant = 'ttt_ring_kernel'
             # SURVEY.md 8(d) terms this kernel covers per evaluation: conv 49*137*128, dense 9*128*128,
             # reward 1152, prediction conv 9*128*128 (multiply-adds x2)
             self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)

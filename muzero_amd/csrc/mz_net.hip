@@ -14,7 +14,7 @@
 // oracle.  Only CartPole batches beyond kCart16MaxBatch take the older f32-MFMA row-tile kernel (cartpole_kernel).
 //
 // TicTacToe (hidden = 3x3x128):
-//   job kernel (ttt_job_kernel_w, 64 games x a group of board cells of nearly equal cost): the 3x3 `same` conv as chained
+//   job kernel (ttt_ring_kernel, 64 games x a group of board cells of nearly equal cost): the 3x3 `same` conv as chained
 //     128x128 stages over the neighbour cells' hidden rows, gathered straight from the [N+1][T][H] hidden tensor by
 //     parent block (no gather copy); the one-hot action planes collapse into a per-(action, cell) bias table; Dense
 //     128->128; writes hidden', the reward-head partial dots and the prediction conv's partial product of its cells.
@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <mutex>
 #include <vector>
@@ -171,9 +172,9 @@ struct TttDev {
     const float* dyn_conv_s;    // [9 taps] x split-f16 fragments for v_mfma_f32_16x16x32_f16 (Packer::add_split16):
     const float* dyn_dense_s;   //   the job kernel's operands (hidden channels 0..127 of the conv)
     const float* pred_conv_s;   // [9 cells]
-    const int4* job_desc;       // stage descriptors of the four uniform-cost jobs (ttt_job_kernel_w)
-    int job_first[5];           // job j owns descriptors [job_first[j], job_first[j+1])
     int job_cells[4][3];        // the cells of job j, -1 = none
+    const int4* ring_desc;      // the jobs as stages of ttt_ring_kernel: (kind, cell, weight matrix, source cell)
+    int ring_first[5];          // job j owns descriptors [ring_first[j], ring_first[j+1])
     float dyn_reward_b, pred_value_b;
     int* range_flag;            // raised when a kernel splits a value outside the split-f16 domain (mz_net_status)
 };
@@ -230,11 +231,22 @@ __device__ __forceinline__ void note_range(float vmax, int* range_flag) {
     if (!(vmax <= kSplitMax)) atomicOr(range_flag, 1);
 }
 
+// acc += acx / 2048: the cross terms of a split-f16 accumulation join the h x h terms once, at its end
+__device__ __forceinline__ void fold4(f32x4 (&acc)[4], const f32x4 (&acx)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
+}
+
+__device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // ---- the TicTacToe job kernel
 // Recurrent inference, uniform-cost jobs.  A job = 64 games x a group of board cells chosen so that every workgroup runs
 // 16-18 GEMM stages: {centre, corner 0} = 11+6, {edges 1,3} = 8+8, {edges 5,7} = 8+8, {corners 2,6,8} = 6+6+6 (a cell
 // costs its valid conv taps + Dense + prediction-conv term).  4096 games -> 256 jobs, one 512-thread workgroup per CU.
-// Stage s multiplies with the weights requested during stage s-1 (in-place register ring) and the tile gathered during
+// Stage s multiplies with the weights requested during stage s-1 (in-place register ring) and a tile gathered during
 // stages s-2 / s-1.  A workgroup loads every weight fragment once for its 64 rows (a 32-row tile was bound by the bytes
 // a CU pulls through its vector-memory path): wave v owns output columns 16v .. 16v+15
 // of all 64 rows, as four 16-row blocks on v_mfma_f32_16x16x32_f16 (weights as the row operand, so a lane holds four
@@ -252,39 +264,67 @@ __device__ __forceinline__ void load_bw(BFragW& b, const float* __restrict__ Ws,
     for (int j = 0; j < 8; ++j) b.v[j] = wp[j * 512];
 }
 
+// How a workgroup's stages follow each other (ttt_ring_kernel): every stage reads one 64 x 128 split tile; the tiles live in a ring of three: stage d reads tile d % 3, whatever wrote it
+// (the gather of a neighbour cell's hidden rows for a conv tap, the last tap's epilogue for the Dense stage, the Dense
+// epilogue for the prediction-conv stage).  With three tiles the gather for stage d+1 can be committed in the MIDDLE of
+// stage d (after k-step 1) and made visible by a barrier there: the waves that are slowest past the previous barrier read
+// tiles (d-1) % 3 or d % 3, never the one being written.  A stage whose successor is a gathered tap therefore ends by
+// reading the successor's first fragments (k-step 3) and the successor starts with its MFMAs, no barrier or LDS latency
+// in between; only the two stages whose tile comes from an epilogue (Dense, prediction conv) start cold behind an
+// end-of-stage barrier.  acx (the cross terms) is folded into acc once per accumulation, not once per stage.
+// Stage kinds of the descriptors (TttDev::ring_desc: .x kind, .y cell, .z weight matrix, .w source cell):
+constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3, kRingPred = 4;
+
+// a gathered tile: the staged 16 bytes of every thread (four per thread: rows idx / 32, 16-byte column idx % 32) into LDS
 template <bool SPLIT_IO>
-__global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B, const float* __restrict__ in_base,
-                                                                 const int* __restrict__ parent_block, long block_stride,
-                                                                 const int* __restrict__ action,
-                                                                 float* __restrict__ out_hidden, float* __restrict__ ppart,
-                                                                 float* __restrict__ rpart) {
-    constexpr int ROWS = 64;
-    __shared__ __attribute__((aligned(16))) _Float16 sTileW[2][ROWS * kLdW];
-    __shared__ __attribute__((aligned(16))) _Float16 sX[ROWS * kLdW];
-    __shared__ __attribute__((aligned(16))) _Float16 sH[ROWS * kLdW];
+__device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[4], unsigned svalid, int tid, float& vmax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
+        const bool ok = (svalid >> i) & 1u;
+        if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
+            *reinterpret_cast<float4*>(buf + r * kLdW + c4 * 8) = ok ? stg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
+            uint2 h, l;
+            split4(v, h, l, vmax);
+            *reinterpret_cast<uint2*>(buf + r * kLdW + c4 * 4) = h;
+            *reinterpret_cast<uint2*>(buf + r * kLdW + 128 + c4 * 4) = l;
+        }
+    }
+}
+
+template <bool SPLIT_IO>
+__global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B, const float* __restrict__ in_base,
+                                                                const int* __restrict__ parent_block, long block_stride,
+                                                                const int* __restrict__ action,
+                                                                float* __restrict__ out_hidden, float* __restrict__ ppart,
+                                                                float* __restrict__ rpart) {
+    constexpr int ROWS = 64, TILE = ROWS * kLdW;
+    __shared__ __attribute__((aligned(16))) _Float16 sRing[3 * TILE];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
     __shared__ __attribute__((aligned(16))) float sBias[11 * 128];   // conv bias + action-plane bias of the current cell,
                                                      // per action; [9*128..]: the cell's 128 reward-head weights;
                                                      // [10*128..]: the dense layer's bias
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
-    auto tile = [&](int b) { return sTileW[b]; };
+    __shared__ float4 sAccP[4 * kThreadsW];          // prediction-conv partial, summed over the job's cells: slot [m][tid]
+                                                     // belongs to thread tid alone (registers are the scarce resource)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (B + ROWS - 1) / ROWS;
     const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
     const int job = bi & 3, rb = (bi >> 2) * 8 + xl;       // the four jobs of a row block share an XCD (its L2)
     if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
     const int row0 = rb * ROWS;
-    const int dbase = w.job_first[job], d1 = w.job_first[job + 1] - dbase;
-    const int n16 = lane & 15, g = lane >> 4;
-    const int lcol = wave * 16 + 4 * g;              // this lane's four columns: lcol .. lcol + 3
+    const int dbase = w.ring_first[job], d1 = w.ring_first[job + 1] - dbase;
+    const int n16 = lane & 15;
     const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_s) + wave * 64 + lane;
 
     if (tid < 128) sBias[10 * 128 + tid] = w.dyn_dense_b[tid];
     BFragW bw;
-    typedef int __attribute__((ext_vector_type(4))) Desc;      // .x kind | flags, .y cell, .z tap, .w source cell
+    typedef int __attribute__((ext_vector_type(4))) Desc;
     typedef const __attribute__((address_space(4))) Desc* DescPtr;
-    const DescPtr desc = (DescPtr)w.job_desc + dbase;
+    const DescPtr desc = (DescPtr)w.ring_desc + dbase;
     const Desc D0 = desc[0];
     load_bw(bw, w.dyn_conv_s + (size_t)D0.z * 16384, lane, wave);
     if (tid < ROWS) {
@@ -312,30 +352,13 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
     }
     float4 stg[4];
     float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
-    auto commit = [&](_Float16* buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
-            const bool ok = (svalid >> i) & 1u;
-            if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
-                *reinterpret_cast<float4*>(buf + r * kLdW + c4 * 8) = ok ? stg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const float v[4] = {ok ? stg[i].x : 0.f, ok ? stg[i].y : 0.f, ok ? stg[i].z : 0.f, ok ? stg[i].w : 0.f};
-                uint2 h, l;
-                split4(v, h, l, vmax);
-                *reinterpret_cast<uint2*>(buf + r * kLdW + c4 * 4) = h;
-                *reinterpret_cast<uint2*>(buf + r * kLdW + 128 + c4 * 4) = l;
-            }
-        }
-    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
-    commit(tile(0));
-    {   // stage 1's tile, if it gathers one, is on its way while stage 0 starts
-        const Desc D1 = desc[d1 > 1 ? 1 : 0];
-        const int src1 = (d1 > 1 && (D1.x & 7) == 0) ? D1.w * 128 : 0;
+    ring_commit<SPLIT_IO>(sRing, stg, svalid, tid, vmax);
+    {   // stage 1's tile (a tap: every cell has at least four) is on its way while stage 0 starts
+        const Desc D1 = desc[1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src1);
+        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D1.w * 128);
     }
     __syncthreads();
 
@@ -344,38 +367,39 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
     int lact[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) lact[m] = sAct[16 * m + n16];
-    f32x4 acc[4], accp[4];                           // accp: prediction-conv partial, summed over the job's cells
+    f32x4 acc[4], acx[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int buf = 0;
-    Desc Dc = D0, Dn = desc[d1 > 1 ? 1 : 0], Dn2 = desc[d1 > 2 ? 2 : 0];
+    for (int m = 0; m < 4; ++m) sAccP[m * kThreadsW + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 af[2][4][2];                              // activation fragments: ring over k-steps, carried across stages
+    int cur = 0, nxt = 1;                            // ring positions of this stage's and the next stage's tile
+    Desc Dc = D0, Dn = desc[1], Dn2 = desc[2];
     MZ_TRACE_DECL;
     MZ_TRACE_NW(0);                                  // prologue
+
 #pragma unroll 1
     for (int d = 0; d < d1; ++d) {
+        // Everything below derives its lane geometry from a copy of the thread index the compiler cannot see through:
+        // hoisted out of the loop, the dozens of per-lane addresses and masks of the epilogues would not fit the 256
+        // registers a wavefront has here (they spilled); recomputed where they are used they cost a few VALU ops.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4, lcol = wave * 16 + 4 * g;
+        const int kind = Dc.x, cell = Dc.y;
         const bool has_next = d + 1 < d1;
-        const bool gather2 = d + 2 < d1 && (Dn2.x & 7) == 0;
-        const int nsrc2 = Dn2.w;
-        const int kind = Dc.x & 7, cell = Dc.y;
-        const int nkind = has_next ? Dn.x & 7 : kind;
-        const bool first_tap = (Dc.x & 8) != 0, last_tap = (Dc.x & 16) != 0;
-        const int ntap = has_next ? Dn.z : Dc.z, ncell = has_next ? Dn.y : Dc.y;
+        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on: a scalar load with the
+                                                                // whole stage to arrive in
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
-        const float* wn = nkind == 0 ? w.dyn_conv_s + (size_t)ntap * 16384
-                        : nkind == 1 ? w.dyn_dense_s : w.pred_conv_s + (size_t)ncell * 16384;
-        const float4* wnext = wlane + (wn - w.dyn_conv_s) / 4;
-        const bool gather = has_next && nkind == 0;
-        const _Float16* sA = kind == 0 ? tile(buf) : kind == 1 ? sX : sH;
-        if (kind == 1 || first_tap) {
-            asm volatile("");
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        const float4* wnext = wlane + (size_t)(has_next ? Dn.z : Dc.z) * 4096;
+        const bool primed = d > 0 && kind <= kRingTapLast;       // af[0] holds this stage's first fragments already
+        const bool commit = has_next && Dn.x <= kRingTapLast;    // the next stage is a gathered tap: its tile is committed
+                                                                 // after k-step 1, a barrier follows, k-step 3 reads its
+                                                                 // first fragments
+        const bool load2 = d + 2 < d1 && Dn2.x <= kRingTapLast;  // request the tile of the stage after the next
+        const int src2 = Dn2.w * 128;
         float bt[3];
-        if (kind == 0 && first_tap) {
+        if (kind == kRingTapFirst) {
             // first tap of a cell: its bias table for all nine actions and its reward weights, requested ahead of this
-            // stage's weight loads and parked in LDS at the end of the stage (a load issued in an epilogue would wait behind the next
-            // stage's weight loads: vmcnt is in-order)
+            // stage's weight loads and parked in LDS at the end of the stage (vmcnt is in-order)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int idx = tid + kThreadsW * i;
@@ -384,24 +408,22 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                                          : 0.f;
             }
         }
-        if (kind == 2) {
+        if (kind == kRingTapFirst || kind >= kRingDense) {       // a new accumulation
             asm volatile("");
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = accp[m];
+            zero4(acc);
+            zero4(acx);
         }
         MZ_TRACE_NW(1);                              // stage set-up
         {   // ---- the stage's MFMAs: 4 k-steps x 4 row blocks x 3
-            const _Float16* ap = sA + n16 * kLdW + 8 * g;
-            f32x4 acx[4];
+            const _Float16* ap = sRing + cur * TILE + n16 * kLdW + 8 * g;
+            const _Float16* np = sRing + nxt * TILE + n16 * kLdW + 8 * g;
+            if (!primed) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float4 af[2][4][2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
-                af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+                for (int m = 0; m < 4; ++m) {
+                    af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+                    af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+                }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the priming reads come first
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (s + 1 < 4) {
@@ -409,6 +431,12 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     for (int m = 0; m < 4; ++m) {
                         af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
                         af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+                    }
+                } else if (commit) {                 // the next stage's first fragments (its tile is behind the barrier)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        af[0][m][0] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW);
+                        af[0][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
                     }
                 }
                 const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
@@ -419,58 +447,51 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
                     acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[m], 0, 0, 0);
                     acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[m], 0, 0, 0);
                 }
-                bw.v[2 * s] = wnext[(2 * s) * 512];  // in-place ring: the next stage's fragments
+                bw.v[2 * s] = wnext[(2 * s) * 512];  // in-place ring: the next stage's weight fragments
                 bw.v[2 * s + 1] = wnext[(2 * s + 1) * 512];
                 // pin the interleave: the next k-step's eight fragment reads, this k-step's twelve MFMAs, its VMEM reads
                 if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                if (s == 1 && gather) commit(tile(buf ^ 1));     // the tile requested during the previous stage
-                if (s == 2) {                                    // the tile two stages ahead
-                    const int src = gather2 ? nsrc2 * 128 : 0;
+                if (s == 1 && commit) {              // the tile requested during the previous stage, then the barrier
+                    ring_commit<SPLIT_IO>(sRing + nxt * TILE, stg, svalid, tid, vmax);
+                    __syncthreads();
+                }
+                if (s == 2 && load2) {               // the tile two stages ahead
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src2);
                 }
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
         }
         MZ_TRACE_NW(2);                              // MFMA section
         __builtin_amdgcn_sched_barrier(0);
-        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on
-        if (kind == 2) {
-            asm volatile("");
+        if (kind == kRingTapFirst) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) accp[m] = acc[m];
-        }
-        if (kind == 0) {
-            if (first_tap) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int idx = tid + kThreadsW * i;
-                    if (idx < 10 * 128) sBias[idx] = bt[i];
-                }
+            for (int i = 0; i < 3; ++i) {
+                const int idx = tid + kThreadsW * i;
+                if (idx < 10 * 128) sBias[idx] = bt[i];
             }
-            if (last_tap) {       // last tap: + bias, relu -> sX (games/tictactoe.py:189)
+        } else if (kind == kRingTapLast) {   // last tap: + bias, relu -> the Dense stage's tile (games/tictactoe.py:189)
+            fold4(acc, acx);
+            _Float16* sX = sRing + nxt * TILE;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float4 bq = *reinterpret_cast<const float4*>(sBias + lact[m] * 128 + lcol);
-                    const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
-                                        fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
-                    uint2 h, l;
-                    split4(v, h, l, vmax);
-                    _Float16* row = sX + (16 * m + n16) * kLdW + lcol;
-                    *reinterpret_cast<uint2*>(row) = h;
-                    *reinterpret_cast<uint2*>(row + 128) = l;
-                }
+            for (int m = 0; m < 4; ++m) {
+                const float4 bq = *reinterpret_cast<const float4*>(sBias + lact[m] * 128 + lcol);
+                const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
+                                    fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
+                uint2 h, l;
+                split4(v, h, l, vmax);
+                _Float16* row = sX + (16 * m + n16) * kLdW + lcol;
+                *reinterpret_cast<uint2*>(row) = h;
+                *reinterpret_cast<uint2*>(row + 128) = l;
             }
             MZ_TRACE_NW(3);                          // epilogue
             __syncthreads();
             MZ_TRACE_NW(4);                          // barrier
-            if (gather) buf ^= 1;
-        } else if (kind == 1) {   // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+        } else if (kind == kRingDense) {     // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
+            fold4(acc, acx);
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
+            _Float16* sH = sRing + nxt * TILE;
             {
                 const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol);
                 const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol);
@@ -503,42 +524,45 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_job_kernel_w(TttDev w, int B
             MZ_TRACE_NW(3);
             __syncthreads();
             MZ_TRACE_NW(4);
-            if (SPLIT_IO) {                        // sH is the row image the workspace wants: copied out 16 bytes a thread
+            if (SPLIT_IO) {                        // the tile is the row image the workspace wants: 16 bytes a thread
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
                     if ((svalid >> i) & 1u)
-                        *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + c4 * 4) =
-                            *reinterpret_cast<const float4*>(sH + r * kLdW + c4 * 8);
+                        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(sH + r * kLdW + c4 * 8),
+                                                    reinterpret_cast<f32x4*>(ocell + (unsigned)r * 1152u + c4 * 4));
                 }
             }
             if (tid < ROWS) {
-                int grow = row0 + tid;
-                asm volatile("" : "+v"(grow));
                 if ((rowmask >> tid) & 1ull) {
                     float rs = 0.f;
 #pragma unroll
                     for (int v8 = 0; v8 < 8; ++v8) rs += sRew[v8 * ROWS + tid];
-                    rpart[(size_t)grow * 9 + cell] = rs;
+                    rpart[(size_t)(row0 + tid) * 9 + cell] = rs;
                 }
             }
-        } else {                  // this cell's term of the prediction conv (games/tictactoe.py:201) stays in accp
-            if (!has_next) {      // end of the job: one partial per (game, job)
-                int prow = row0;
-                asm volatile("" : "+s"(prow));
-                float* const pjob = ppart + (size_t)prow * 1152 + job * 128;
+            MZ_TRACE_NW(5);                          // after the barrier
+        } else if (kind == kRingPred) {      // this cell's term of the prediction conv (games/tictactoe.py:201) joins sAccP
+            fold4(acc, acx);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 q = sAccP[m * kThreadsW + tid];
+                acc[m] += f32x4{q.x, q.y, q.z, q.w};
+            }
+            if (has_next) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sAccP[m * kThreadsW + tid] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            } else {              // end of the job: one partial per (game, job)
+                float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     if ((rowmask >> (16 * m + n16)) & 1ull)
-                        *reinterpret_cast<float4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) =
-                            make_float4(accp[m][0], accp[m][1], accp[m][2], accp[m][3]);
+                        __builtin_nontemporal_store(acc[m], reinterpret_cast<f32x4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol));
             }
             MZ_TRACE_NW(3);
-            __syncthreads();
-            MZ_TRACE_NW(4);
-            if (gather) buf ^= 1;
         }
-        MZ_TRACE_NW(5);                              // after the barrier
+        cur = nxt;
+        nxt = nxt == 2 ? 0 : nxt + 1;
         Dc = Dn;
         Dn = Dn2;
         Dn2 = Dn3;
@@ -1426,7 +1450,7 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_step_kernel(CartDev w, 
 //   recurrent: gather -> X;  input conv X -> Y;  2 x { conv a: Y -> X;  conv b (+ residual): X -> Y };  hidden' = Y;
 //              prediction conv Y -> X0;  dense X0 -> X1;  heads X1 -> value, logits;   reward = tanh(<hidden', w> + b)
 //   initial:   observation -> X;  conv X -> Y;  dense (per position) Y -> X = hidden;  prediction from X.
-// 16384 games = 256 workgroups, one per CU.  A stage is the job kernel's (ttt_job_kernel_w): wave v owns output columns
+// 16384 games = 256 workgroups, one per CU.  A stage is the job kernel's (ttt_ring_kernel): wave v owns output columns
 // 16v .. 16v+15 of all 64 rows as four 16-row blocks on v_mfma_f32_16x16x32_f16, split-f16 operands; one barrier per
 // LAYER (the tiles a layer writes are not the ones it reads).  The residual stream stays in f32 registers (a lane holds
 // four columns of four rows per position), so a residual add is exact f32, never a re-read of a split image.
@@ -1496,16 +1520,6 @@ __device__ __forceinline__ void stage64(const _Float16* sA, const _Float16* next
 }
 
 // acc += acx / 2048: the cross terms of a finished accumulation
-__device__ __forceinline__ void fold4(f32x4 (&acc)[4], const f32x4 (&acx)[4]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
-}
-
-__device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
 // v[m] = relu(x[m] + bias) of this lane's four columns; split and stored into rows 16 m + n16 of an LDS tile
 __device__ __forceinline__ void store_tile4(const f32x4 (&v)[4], _Float16* tile, int n16, int lcol, float& vmax) {
 #pragma unroll
@@ -1963,7 +1977,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         for (int o = 0; o < 9; ++o) headB[1 + o] = pred_policy_b[o];
         t.dyn_reward_b = dyn_reward_b[0];
         t.pred_value_b = pred_value_b[0];
-        // stage descriptors of the four uniform-cost jobs: (kind | 8*first tap | 16*last tap, cell, tap, source cell)
+        // the four uniform-cost jobs
         static const int kJobCells[4][3] = {{4, 0, -1}, {1, 3, -1}, {5, 7, -1}, {2, 6, 8}};
         std::vector<float> desc;      // int4 bit patterns stored in the float buffer
         auto push = [&](int a, int b, int c, int d) {
@@ -1974,9 +1988,12 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
                 desc.push_back(f);
             }
         };
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
             for (int ci = 0; ci < 3; ++ci) t.job_cells[j][ci] = kJobCells[j][ci];
-            t.job_first[j] = (int)desc.size() / 4;
+        // their stages for the ring kernel: (kind, cell, weight matrix, source cell); matrices 0..8 = conv taps,
+        // 9 = Dense, 10 + c = prediction conv of cell c (consecutive in the packed buffer, checked below)
+        for (int j = 0; j < 4; ++j) {
+            t.ring_first[j] = (int)desc.size() / 4;
             for (int ci = 0; ci < 3; ++ci) {
                 const int c = kJobCells[j][ci];
                 if (c < 0) continue;
@@ -1987,27 +2004,38 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
                 }
                 for (int i = 0; i < nv; ++i) {
                     const int tp = valid[i];
-                    push(0 | (i == 0 ? 8 : 0) | (i == nv - 1 ? 16 : 0), c, tp, (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
+                    push(i == 0 ? kRingTapFirst : i == nv - 1 ? kRingTapLast : kRingTap, c, tp,
+                         (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
                 }
-                push(1, c, 0, 0);
-                push(2, c, 0, 0);
+                push(kRingDense, c, 9, 0);
+                push(kRingPred, c, 10 + c, 0);
             }
         }
-        t.job_first[4] = (int)desc.size() / 4;
-        put(reinterpret_cast<const float*&>(t.job_desc), pk.add(desc));
+        t.ring_first[4] = (int)desc.size() / 4;
+        put(reinterpret_cast<const float*&>(t.ring_desc), pk.add(desc));
         put(t.pred_head_p, pk.add_split16(headW.data(), 16, 16));
         put(t.pred_head_b, pk.add(headB));
         auto add_series = [&](const float*& field, int count, auto&& one) {      // `count` matrices, consecutive
+            size_t first = 0;
             for (int i = 0; i < count; ++i) {
                 const size_t o = one(i);
-                if (i == 0) put(field, o);
+                if (i == 0) put(field, first = o);
             }
+            return first;
         };
         add_series(t.pred_conv_h, 9, [&](int c) { return pk.add_split_f16(pred_conv + (size_t)c * 128 * 128, 128); });
         put(t.rep_dense_h, pk.add_split_f16(rep_dense, 128));
-        add_series(t.dyn_conv_s, 9, [&](int tp) { return pk.add_split16(dyn_conv + (size_t)tp * 137 * 128, 128, 128); });
-        put(t.dyn_dense_s, pk.add_split16(dyn_dense, 128, 128));
-        add_series(t.pred_conv_s, 9, [&](int c) { return pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128); });
+        const size_t o_conv =
+            add_series(t.dyn_conv_s, 9, [&](int tp) { return pk.add_split16(dyn_conv + (size_t)tp * 137 * 128, 128, 128); });
+        const size_t o_dense = pk.add_split16(dyn_dense, 128, 128);
+        put(t.dyn_dense_s, o_dense);
+        const size_t o_pred =
+            add_series(t.pred_conv_s, 9, [&](int c) { return pk.add_split16(pred_conv + (size_t)c * 128 * 128, 128, 128); });
+        // the ring kernel addresses the nineteen matrices as dyn_conv_s + 16384 * index
+        if (o_dense != o_conv + 9 * 16384 || o_pred != o_dense + 16384) {
+            delete net;
+            return mz::fail(MZ_ERR_STATE, "packed TicTacToe stage matrices are not consecutive");
+        }
     } else if (kind == MZ_NET_ATARI_SHAPED) {
         AtariDev& a = net->atari;
         const float* rep_conv = take(3 * 128 * 128);   // (3,128,128)
@@ -2282,11 +2310,11 @@ static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, 
     hipStream_t st = net->stream;
     const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
     if (split_hidden)
-        ttt_job_kernel_w<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                           out_hidden, ppart, rpart);
+        ttt_ring_kernel<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                          out_hidden, ppart, rpart);
     else
-        ttt_job_kernel_w<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                            out_hidden, ppart, rpart);
+        ttt_ring_kernel<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                           out_hidden, ppart, rpart);
 }
 
 // split_hidden: the hidden rows read and written are the split images of a native move's workspace (TicTacToe)

@@ -1,4 +1,4 @@
-"""The arithmetic of the split-f16 job kernel (muzero_amd/csrc/mz_net.hip, ttt_job_kernel_h), modelled in NumPy and held
+"""The arithmetic of the split-f16 job kernel (muzero_amd/csrc/mz_net.hip, ttt_ring_kernel), modelled in NumPy and held
 to the fp64 network oracle: every f32 operand v is carried as h = f16(v), l = f16((v - h) * 2048), a product is
 ah*bh + (ah*bl + al*bh)/2048 accumulated in f32.  CPU only; the kernel itself is tested in test_net_gpu.py."""
 import numpy as np

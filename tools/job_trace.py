@@ -28,3 +28,13 @@ for i, nm in enumerate(NAMES):
     if not nm: continue
     print(f'  {nm:14s} mean {clk[:, i].mean():8.0f}  max {clk[:, i].max():8.0f}   x{cnt[:, i].mean():5.1f}  -> {clk[:, i].sum() / max(cnt[:, i].sum(), 1):7.0f} each')
 print('  total          mean %8.0f  max %8.0f' % (clk.sum(1).mean(), clk.sum(1).max()))
+if not TREE:
+    # per job (blockIdx = 8 * (4 * rbhi + job) + xcd lane; 8 wavefronts per workgroup): which job is the long pole
+    idx = np.nonzero(used)[0]
+    job = ((idx // 8) >> 3) & 3
+    tot = clk.sum(1)
+    for j in range(4):
+        sel = job == j
+        if sel.any():
+            print(f'  job {j}: {int(sel.sum())} wavefronts, total mean {tot[sel].mean():8.0f}  max {tot[sel].max():8.0f}; '
+                  + ' '.join(f'{NAMES[i][:8]}={clk[sel, i].mean():.0f}' for i in range(6)))
