@@ -163,6 +163,17 @@ class HipEvents:
         self.used.append(ev)
         return ev
 
+    def reserve(self, n):
+        """Create n events now and record each once: the first process on a fresh box has been seen to stall ~40 ms
+        somewhere past its 30th event, which must not happen inside a timed region."""
+        fresh = [self.new() for _ in range(n)]
+        for ev in fresh:
+            self.record(ev)
+        torch.cuda.synchronize()
+        for ev in fresh:
+            self.used.remove(ev)
+            self.free.append(ev)
+
     def record(self, ev=None):
         ev = ev if ev is not None else self.new()
         stream = self.ct.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -354,12 +365,13 @@ def main():
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sync-every', type=int, default=0, help='synchronise the host every n timed steps (0 = never)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help="weak: the workload's games PER GPU (default); strong: the workload's games in total, sharded "
                          "over the ranks (BASELINE.json configs[2] read as 4096 games over 1/2/4/8 GPUs)")
     ap.add_argument('--lanes', type=int, default=1,
                     help='split the games of a GPU into this many lockstep lanes on separate HIP streams')
-    ap.add_argument('--event-every', type=int, default=4,
+    ap.add_argument('--event-every', type=int, default=10,
                     help='record the per-kernel HIP events on every K-th timed step (each record costs stream time)')
     ap.add_argument('--event-stride', type=int, default=5,
                     help='... and there on every S-th simulation only')
@@ -390,6 +402,8 @@ def main():
     move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride) if with_net
             else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
 
+    timed_steps = (args.steps + args.event_every - 1) // args.event_every + 1
+    (move.hooks.ev if with_net else move.hip_events).reserve(timed_steps * 3 * (wl['N'] // stride + 1))
     for i in range(args.warmup):
         move.run(timed_events=(i == 0))              # the first warm-up step also warms the event-recording path
     if with_net:
@@ -405,6 +419,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         move.run(timed_events=(i % args.event_every == 0))
+        if args.sync_every and (i + 1) % args.sync_every == 0:
+            torch.cuda.synchronize()
     if with_net:
         move.finish()
     torch.cuda.synchronize()
