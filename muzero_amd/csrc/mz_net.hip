@@ -1614,6 +1614,11 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
     float4 af[2][4][2];                              // the activation-fragment ring (stage64)
     constexpr int kSF = kAtariStageFloats / 4;       // float4 per stage matrix
     constexpr int NL = INITIAL ? 1 : 5;
+    float4 rwq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};     // reward-head weights of this lane's
+    if (!INITIAL) {                                                                          // columns, requested early
+        rwq[0] = *reinterpret_cast<const float4*>(w.dyn_reward_w + lcol);
+        rwq[1] = *reinterpret_cast<const float4*>(w.dyn_reward_w + 128 + lcol);
+    }
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) {
         const _Float16* src0 = sT[(l & 1) ? 2 : 0];
@@ -1678,18 +1683,18 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
         }
         __syncthreads();
     }
-    {   // hidden state out, f32, from the residual registers; the reward head's partial dot from the same registers
+    {   // hidden state out, f32, from the residual registers (streaming stores: nothing here reads them back); the reward
+        // head's partial dot from the same registers
         float rdot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!INITIAL) rw = *reinterpret_cast<const float4*>(w.dyn_reward_w + p * 128 + lcol);
+            const float4 rw = rwq[p];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 x = res[p][m];
                 if ((rowmask >> (16 * m + n16)) & 1ull)
-                    *reinterpret_cast<float4*>(out_hidden + (size_t)(row0 + 16 * m + n16) * 256 + p * 128 + lcol) =
-                        make_float4(x[0], x[1], x[2], x[3]);
+                    __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(out_hidden + (size_t)(row0 + 16 * m + n16) * 256 +
+                                                                            p * 128 + lcol));
                 if (!INITIAL)
                     rdot[m] = __builtin_fmaf(x[3], rw.w, __builtin_fmaf(x[2], rw.z, __builtin_fmaf(x[1], rw.y, __builtin_fmaf(x[0], rw.x, rdot[m]))));
             }
