@@ -387,6 +387,33 @@ int mz_history_record_move(void* stream, const mz_history_t* hist, const int32_t
 int mz_history_flush(void* stream, const mz_history_t* live, const mz_history_t* finished, const int32_t* steps,
                      const int32_t* ended, int32_t* serial, int64_t* counters, int32_t* flush_dst, int32_t* reset_mask);
 
+/* The same bookkeeping with the environment inside, for a batch that is refilled every move (SelfPlayEngine.
+ * play_continuous): fourteen small launches a move become four.  No counterpart of their own in the reference: they are
+ * the calls above and the mz_env_* calls, fused.
+ *   mz_env_t: one of the two batched environments as caller-owned state (the arrays of mz_env_ttt_* / mz_env_cartpole_*);
+ *       restart_state [G,4] f64 = the states restarted CartPole games begin in (NULL for TicTacToe).
+ *   mz_selfplay_turnover = observe -> mz_history_record_observation -> mz_history_flush -> reset of the finished slots ->
+ *       observe -> record_observation -> mz_dirichlet_from_gamma (when gamma != NULL), and out_temperature[g] =
+ *       temperature while the slot's game has played fewer than freezing_moves moves, else 0 (config.py:153-157).
+ *       Outputs: the search's inputs for the next move.
+ *   mz_selfplay_step_record = mz_env_*_step -> mz_history_record_move. */
+enum { MZ_ENV_TICTACTOE = 1, MZ_ENV_CARTPOLE = 2 };
+typedef struct mz_env {
+    int32_t kind, num_games;
+    void* state;                 /* TicTacToe: int8 board [G,9]; CartPole: f64 [G,4] */
+    int32_t* to_play;            /* [G] (TicTacToe; ignored for CartPole) */
+    int32_t* steps;              /* [G] */
+    int32_t* ended;              /* [G] */
+    const double* restart_state; /* CartPole: [G,4] */
+} mz_env_t;
+int mz_selfplay_turnover(void* stream, const mz_env_t* env, const mz_history_t* live, const mz_history_t* finished,
+                         int32_t* serial, int64_t* counters, int32_t* flush_dst, int32_t* reset_mask, const double* gamma,
+                         int32_t freezing_moves, double temperature, float* out_observation, int32_t* out_legal,
+                         int32_t* out_n_legal, double* out_noise, double* out_temperature);
+int mz_selfplay_step_record(void* stream, const mz_env_t* env, const mz_history_t* live, const int32_t* action,
+                            const double* root_value, const float* policy, float* out_reward, int32_t* out_status,
+                            int32_t* any_illegal);
+
 /* The root noise of a batch of games from independent Gamma(alpha, 1) draws (the caller's RNG): out_noise[g, k] =
  * gamma[g, k] / sum(gamma[g, 0..n_legal[g])) for k < n_legal[g], else 0 -- np.random.dirichlet([alpha] * n_children)
  * (agent.py:172) for every game in one launch, in the layout mz_add_root_noise / mz_search_move take.  [G, A] f64. */

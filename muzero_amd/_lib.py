@@ -39,6 +39,15 @@ class History(ctypes.Structure):
                 ('root_values', c_void_p), ('policies', c_void_p), ('lengths', c_void_p)]
 
 
+class Env(ctypes.Structure):
+    """mz_env_t"""
+    _fields_ = [('kind', c_int32), ('num_games', c_int32), ('state', c_void_p), ('to_play', c_void_p),
+                ('steps', c_void_p), ('ended', c_void_p), ('restart_state', c_void_p)]
+
+
+MZ_ENV_TICTACTOE, MZ_ENV_CARTPOLE = 1, 2
+
+
 class ReplayConfig(ctypes.Structure):
     """mz_replay_config_t"""
     _fields_ = [('num_games', c_int32), ('max_moves', c_int32), ('num_actions', c_int32), ('num_unroll_steps', c_int32),
@@ -105,6 +114,10 @@ PROTOTYPES = {
     'mz_history_record_move': (ctypes.c_int, [c_void_p, ctypes.POINTER(History)] + [c_void_p] * 6),
     'mz_dirichlet_from_gamma': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'mz_history_flush': (ctypes.c_int, [c_void_p, ctypes.POINTER(History), ctypes.POINTER(History)] + [c_void_p] * 6),
+    'mz_selfplay_turnover': (ctypes.c_int, [c_void_p, ctypes.POINTER(Env), ctypes.POINTER(History), ctypes.POINTER(History),
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_double,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_selfplay_step_record': (ctypes.c_int, [c_void_p, ctypes.POINTER(Env), ctypes.POINTER(History)] + [c_void_p] * 6),
     'mz_replay_targets': (ctypes.c_int, [c_void_p, ctypes.POINTER(ReplayConfig)] + [c_void_p] * 12),
     'mz_env_cartpole_step': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),

@@ -365,12 +365,17 @@ class SelfPlayEngine:
             if isinstance(lane.network, Network):
                 lane.network.check_range()           # an activation outside the kernels' numeric domain
 
-    def play_continuous(self, num_games: int, max_moves: Optional[int] = None, check_every: int = 8) -> BatchedHistory:
+    def play_continuous(self, num_games: int, max_moves: Optional[int] = None, check_every: int = 32,
+                        fused: bool = True) -> BatchedHistory:
         """The reference agent's outer loop (agent_services.py:47-54: play a game, hand its history over, start the next
         one at once) for G slots: a slot whose game ends is flushed to the finished store and restarted before the next
         search, so every move searches a full batch of live games.  Returns the first `num_games` games started (in
         start order: slot order within a wave of restarts) as one BatchedHistory; games still in flight at the end are
-        dropped.  Slots are at different moves of their games, so the temperature is per slot (config.py:153-157)."""
+        dropped.  Slots are at different moves of their games, so the temperature is per slot (config.py:153-157).
+        check_every: the longest run of moves between two looks at the finished-games counter (a look synchronises; the
+        fused loop spaces its looks by the rate at which games have been finishing and looks every move near the end).
+        fused=False takes the one-call-per-step entry points instead of the two fused ones (same games for the same random
+        draws; the draws are made in a different order, so a seed gives different games)."""
         env, cfg, dev, G = self.env, self.config, self.device, self.G
         lib = _lib.load()
         M = int(max_moves if max_moves is not None else cfg.mcts_config.max_moves)
@@ -394,7 +399,48 @@ class SelfPlayEngine:
         stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         env.reset()
         moves = 0
-        while True:
+        fused = bool(fused and getattr(env, 'supports_fused', False))
+        if fused:
+            # Three small launches a move instead of fourteen: the bookkeeping between two searches is one call
+            # (mz_selfplay_turnover: two kernels), the environment step and the move record another.
+            # The random draws (root-noise gammas, the uniforms of the action sampling, CartPole restart states) are made
+            # for `block` moves in one launch each.
+            block, next_check = 16, 0
+            alpha = self.alpha.unsqueeze(0).expand(block, G, self.A).contiguous()
+            alpha_is_one = float(cfg.mcts_config.root_dirichlet_alpha) == 1.0
+            while True:
+                k = moves % block
+                if k == 0:
+                    if alpha_is_one:         # Gamma(1, 1) is the standard exponential (numpy's own path for shape 1)
+                        gammas = torch.empty_like(alpha).exponential_(generator=self.generator)
+                    else:
+                        gammas = torch._standard_gamma(alpha, generator=self.generator)
+                    us = torch.rand(block, G, dtype=torch.float64, device=dev, generator=self.generator)
+                    restarts = env.draw_restart_states(block)
+                gamma, u = gammas[k], us[k]
+                env_s = env.as_struct(None if restarts is None else restarts[k])
+                _lib.check(lib.mz_selfplay_turnover(
+                    stream(), ctypes.byref(env_s), ctypes.byref(live_s), ctypes.byref(done_s), serial.data_ptr(),
+                    counters.data_ptr(), flush_dst.data_ptr(), reset_mask.data_ptr(), gamma.data_ptr(), freezing, t_cfg,
+                    env.observation.data_ptr(), env.legal.data_ptr(), env.n_legal.data_ptr(), self._noise.data_ptr(),
+                    self.temperature.data_ptr()))
+                if moves >= next_check:
+                    stored = int(counters[1].item())                                        # synchronises
+                    if stored >= num_games:
+                        break
+                    # the next look: three quarters of the way to the expected end at the rate seen so far (a
+                    # synchronisation drains the launch queue, ~0.2 ms), every move once the end is near
+                    ahead = check_every
+                    if stored > 0 and moves > 0:
+                        ahead = min(check_every, int(0.75 * (num_games - stored) * moves / stored))
+                    next_check = moves + max(1, ahead)
+                _visits, root_value, _minmax, policy, action = self.search.run(env.observation, self._noise, u,
+                                                                               self.temperature, env.legal, env.n_legal)
+                _lib.check(lib.mz_selfplay_step_record(
+                    stream(), ctypes.byref(env_s), ctypes.byref(live_s), action.data_ptr(), root_value.data_ptr(),
+                    policy.data_ptr(), env.reward.data_ptr(), env.status.data_ptr(), env._illegal.data_ptr()))
+                moves += 1
+        while not fused:
             obs, legal, n_legal = env.observe()
             _lib.check(lib.mz_history_record_observation(stream(), ctypes.byref(live_s), env.steps.data_ptr(),
                                                          obs.data_ptr(), env.to_play.data_ptr()))

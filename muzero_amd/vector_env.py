@@ -25,6 +25,7 @@ class VectorEnvironment:
     action_space_size = 0
     num_players = 0
     observation_size = 0
+    supports_fused = False         # as_struct() gives an mz_env_t (the two built-in environments)
 
     def __init__(self, num_games: int, device='cuda') -> None:
         if not torch.cuda.is_available():
@@ -72,6 +73,15 @@ class VectorEnvironment:
             self._illegal.zero_()
             raise MuZeroEnvironmentError('a batched step was handed an illegal action (status == 2 marks the games)')
 
+    def as_struct(self, restart_state: Optional[torch.Tensor] = None):
+        """mz_env_t over this environment's state (for the fused self-play calls); None when the environment has none."""
+        return None
+
+    def draw_restart_states(self, count: int = 1) -> Optional[torch.Tensor]:
+        """The states restarted games begin in, drawn ahead of time for `count` moves ([count, G, ...]; CartPole); None
+        when a restart is deterministic."""
+        return None
+
     def _action_ptr(self, action):
         if (not isinstance(action, torch.Tensor) or action.dtype != torch.int32 or tuple(action.shape) != (self.G,)
                 or action.device != self.device or not action.is_contiguous()):
@@ -85,10 +95,15 @@ class TicTacToeVectorEnv(VectorEnvironment):
     num_players = 2
     observation_size = 27
     max_moves = 9
+    supports_fused = True
 
     def __init__(self, num_games: int, device='cuda') -> None:
         super().__init__(num_games, device)
         self.board = torch.full((self.G, 9), -1, dtype=torch.int8, device=self.device)
+
+    def as_struct(self, restart_state=None):
+        return _lib.Env(_lib.MZ_ENV_TICTACTOE, self.G, self.board.data_ptr(), self.to_play.data_ptr(),
+                        self.steps.data_ptr(), self.ended.data_ptr(), None)
 
     def reset(self) -> None:
         with torch.cuda.device(self.device):
@@ -125,6 +140,7 @@ class CartPoleVectorEnv(VectorEnvironment):
     num_players = 1
     observation_size = 4
     max_moves = 500
+    supports_fused = True
 
     def __init__(self, num_games: int, device='cuda', seed: Optional[int] = None) -> None:
         super().__init__(num_games, device)
@@ -132,6 +148,16 @@ class CartPoleVectorEnv(VectorEnvironment):
         self.generator = torch.Generator(device=self.device)
         if seed is not None:
             self.generator.manual_seed(seed)
+
+    def draw_restart_states(self, count: int = 1):
+        return (torch.rand(count, self.G, 4, dtype=torch.float64, device=self.device, generator=self.generator) - 0.5) * 0.1
+
+    def as_struct(self, restart_state=None):
+        if restart_state is None:
+            restart_state = self.draw_restart_states()[0]
+        self._init_keepalive = restart_state
+        return _lib.Env(_lib.MZ_ENV_CARTPOLE, self.G, self.state.data_ptr(), None, self.steps.data_ptr(),
+                        self.ended.data_ptr(), restart_state.data_ptr())
 
     def reset(self, initial_state: Optional[torch.Tensor] = None) -> None:
         """initial_state [G,4] f64; default U(-0.05, 0.05) like gym's reset."""

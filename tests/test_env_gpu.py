@@ -136,8 +136,8 @@ def test_selfplay_engine_plays_legal_complete_tictactoe_games(lanes):
     assert not torch.equal(again.actions, hist.actions)
 
 
-@pytest.mark.parametrize('lanes', [1, 2])
-def test_selfplay_engine_refills_finished_slots(lanes):
+@pytest.mark.parametrize('lanes,fused', [(1, True), (1, False), (2, True)])
+def test_selfplay_engine_refills_finished_slots(lanes, fused):
     """play_continuous: a slot whose game ends is flushed and restarted before the next search (the reference agent's
     loop, agent_services.py:47-54).  Every stored game -- including the refilled ones -- replays on the host environment
     to the same observations, players, rewards and length; the store holds exactly the first `num_games` games started."""
@@ -149,7 +149,7 @@ def test_selfplay_engine_refills_finished_slots(lanes):
     config = tictactoe.make_config(num_simulations=N)
     net = config.network_config.network_class(config, seed=3)
     engine = SelfPlayEngine(config, net, G, seed=23, lanes=lanes)
-    hist = engine.play_continuous(total, check_every=3)
+    hist = engine.play_continuous(total, check_every=3, fused=fused)
     assert hist.G == total and hist.metadata['slots'] == G and hist.metadata['games_started'] >= total
     games = hist.to_game_histories()
     lengths = hist.lengths.cpu().numpy()
@@ -175,12 +175,13 @@ def test_selfplay_engine_refills_finished_slots(lanes):
         np.testing.assert_array_equal(h.observations[-1], state.observation)
         assert h.to_plays[-1] == state.to_play
     # same seed, same games; the first G games are the ones a plain batch would start with
-    again = SelfPlayEngine(config, net, G, seed=23, lanes=lanes).play_continuous(total, check_every=5)
+    again = SelfPlayEngine(config, net, G, seed=23, lanes=lanes).play_continuous(total, check_every=5, fused=fused)
     for f in hist.FIELDS:
         assert torch.equal(getattr(hist, f), getattr(again, f)), f
 
 
-def test_selfplay_engine_refills_cartpole_with_a_move_cap():
+@pytest.mark.parametrize('fused', [True, False])
+def test_selfplay_engine_refills_cartpole_with_a_move_cap(fused):
     """Slots that reach the move capacity without the episode ending are flushed as truncated games (agent.py:34's
     `len(history) < max_moves`) and restarted like finished ones."""
     from muzero_amd.games import cartpole
@@ -188,7 +189,7 @@ def test_selfplay_engine_refills_cartpole_with_a_move_cap():
     G, N, M, total = 32, 4, 10, 100
     config = cartpole.make_config(num_simulations=N)
     net = config.network_config.network_class(config, seed=1)
-    hist = SelfPlayEngine(config, net, G, seed=2).play_continuous(total, max_moves=M, check_every=4)
+    hist = SelfPlayEngine(config, net, G, seed=2).play_continuous(total, max_moves=M, check_every=4, fused=fused)
     lengths = hist.lengths.cpu().numpy()
     assert hist.G == total and (lengths >= 1).all() and (lengths <= M).all()
     rew, acts = hist.rewards.cpu().numpy(), hist.actions.cpu().numpy()
@@ -198,6 +199,90 @@ def test_selfplay_engine_refills_cartpole_with_a_move_cap():
         assert (rew[:lengths[g], g] == 1.0).all() and (rew[lengths[g]:, g] == 0.0).all()
         assert (np.abs(obs[0, g]) <= 0.05).all()                 # every game starts from a fresh reset state
     np.testing.assert_allclose(hist.policies.cpu().numpy()[0].sum(-1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize('game', ['tictactoe', 'cartpole'])
+def test_fused_selfplay_calls_equal_the_separate_ones(game):
+    """mz_selfplay_turnover / mz_selfplay_step_record against the calls they fuse (observe, record_observation, flush,
+    reset_where, observe, record_observation, dirichlet_from_gamma; step, record_move) on the same random mid-game
+    states, several rounds: environment state, both histories, serials, counters and the search inputs bit for bit."""
+    import ctypes
+    import torch
+    from muzero_amd import _lib
+    from muzero_amd.selfplay import BatchedHistory
+    from muzero_amd.vector_env import CartPoleVectorEnv, TicTacToeVectorEnv
+    lib = _lib.load()
+    G, M, F = 300, 6 if game == 'tictactoe' else 5, 900
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    mk = (lambda: TicTacToeVectorEnv(G, dev)) if game == 'tictactoe' else (lambda: CartPoleVectorEnv(G, dev, seed=1))
+    envs = [mk(), mk()]
+    A, O = envs[0].action_space_size, envs[0].observation_size
+    init = (torch.rand(G, 4, dtype=torch.float64, device=dev, generator=g) - 0.5) * 0.4
+    for e in envs:
+        e.reset(init) if game == 'cartpole' else e.reset()
+    hists = [(BatchedHistory(M, G, (O,), A, dev), BatchedHistory(M, F, (O,), A, dev)) for _ in range(2)]
+    i32 = dict(dtype=torch.int32, device=dev)
+    book = [dict(serial=torch.arange(G, **i32), counters=torch.tensor([G, 0], dtype=torch.int64, device=dev),
+                 dst=torch.empty(G, **i32), mask=torch.empty(G, **i32), noise=torch.zeros(G, A, dtype=torch.float64, device=dev),
+                 temp=torch.zeros(G, dtype=torch.float64, device=dev)) for _ in range(2)]
+    stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    freezing, t_cfg = 3, 0.7
+    for rnd in range(14):
+        gamma = torch._standard_gamma(torch.ones(G, A, dtype=torch.float64, device=dev), generator=g)
+        restart = (torch.rand(G, 4, dtype=torch.float64, device=dev, generator=g) - 0.5) * 0.1
+        # ---- separate calls
+        e, (live, done), b = envs[0], hists[0], book[0]
+        ls, ds = live.as_struct(), done.as_struct()
+        obs, legal, n_legal = e.observe()
+        _lib.check(lib.mz_history_record_observation(stream(), ctypes.byref(ls), e.steps.data_ptr(), obs.data_ptr(),
+                                                     e.to_play.data_ptr()))
+        _lib.check(lib.mz_history_flush(stream(), ctypes.byref(ls), ctypes.byref(ds), e.steps.data_ptr(), e.ended.data_ptr(),
+                                        b['serial'].data_ptr(), b['counters'].data_ptr(), b['dst'].data_ptr(),
+                                        b['mask'].data_ptr()))
+        e.reset_where(b['mask'], restart) if game == 'cartpole' else e.reset_where(b['mask'])
+        obs, legal, n_legal = e.observe()
+        _lib.check(lib.mz_history_record_observation(stream(), ctypes.byref(ls), e.steps.data_ptr(), obs.data_ptr(),
+                                                     e.to_play.data_ptr()))
+        _lib.check(lib.mz_dirichlet_from_gamma(stream(), G, A, gamma.data_ptr(), n_legal.data_ptr(), b['noise'].data_ptr()))
+        b['temp'].copy_(torch.where(e.steps < freezing, torch.tensor(t_cfg, dtype=torch.float64, device=dev),
+                                    torch.tensor(0.0, dtype=torch.float64, device=dev)))
+        # ---- fused
+        e2, (live2, done2), b2 = envs[1], hists[1], book[1]
+        ls2, ds2 = live2.as_struct(), done2.as_struct()
+        es = e2.as_struct(restart)
+        _lib.check(lib.mz_selfplay_turnover(stream(), ctypes.byref(es), ctypes.byref(ls2), ctypes.byref(ds2),
+                                            b2['serial'].data_ptr(), b2['counters'].data_ptr(), b2['dst'].data_ptr(),
+                                            b2['mask'].data_ptr(), gamma.data_ptr(), freezing, t_cfg,
+                                            e2.observation.data_ptr(), e2.legal.data_ptr(), e2.n_legal.data_ptr(),
+                                            b2['noise'].data_ptr(), b2['temp'].data_ptr()))
+        for name in ('observation', 'legal', 'n_legal', 'steps', 'ended', 'to_play'):
+            assert torch.equal(getattr(e, name), getattr(e2, name)), (rnd, name)
+        for k in b:
+            assert torch.equal(b[k], b2[k]), (rnd, k)
+        # ---- a move: random legal actions (some slots get an illegal one in TicTacToe: status 2, nothing recorded)
+        pick = torch.randint(0, A, (G,), generator=g, device=dev, dtype=torch.int32)
+        action = torch.where(n_legal > 0, legal.gather(1, (pick % n_legal.clamp(min=1)).long().unsqueeze(1)).squeeze(1), pick)
+        if game == 'tictactoe':
+            action[::17] = pick[::17]
+        action = action.to(torch.int32).contiguous()
+        root_value = torch.rand(G, dtype=torch.float64, device=dev, generator=g)
+        policy = torch.rand(G, A, device=dev, generator=g)
+        reward = e.step(action)
+        _lib.check(lib.mz_history_record_move(stream(), ctypes.byref(ls), e.steps.data_ptr(), e.status.data_ptr(),
+                                              action.data_ptr(), reward.data_ptr(), root_value.data_ptr(), policy.data_ptr()))
+        _lib.check(lib.mz_selfplay_step_record(stream(), ctypes.byref(es), ctypes.byref(ls2), action.data_ptr(),
+                                               root_value.data_ptr(), policy.data_ptr(), e2.reward.data_ptr(),
+                                               e2.status.data_ptr(), e2._illegal.data_ptr()))
+        for name in ('reward', 'status', 'steps', 'ended', 'to_play', '_illegal'):
+            assert torch.equal(getattr(e, name), getattr(e2, name)), (rnd, name)
+        state = 'board' if game == 'tictactoe' else 'state'
+        assert torch.equal(getattr(e, state), getattr(e2, state)), rnd
+        for h, h2 in zip(hists[0], hists[1]):
+            for f in h.FIELDS:
+                assert torch.equal(getattr(h, f), getattr(h2, f)), (rnd, f)
+    assert int(book[0]['counters'][1].item()) > G          # several waves of games were flushed
+    envs[0]._illegal.zero_(); envs[1]._illegal.zero_()
 
 
 def test_selfplay_engine_cartpole_short_episodes():

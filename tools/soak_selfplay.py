@@ -39,10 +39,10 @@ for name, mod, G, N, max_moves in (('tictactoe', tictactoe, 4096, 25, None), ('c
     torch.cuda.synchronize(); per_move = 20 * G * N / (time.perf_counter() - t0)
     print(f'{name}: search alone: {per_move / 1e6:.1f} M simulations/s per move', flush=True)
     # continuous refill: finished slots restart at once, every move searches a full batch (agent_services.py:47-54)
-    total = 4 * G
+    total = 8 * G
     for b in range(batches):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        hist = engine.play_continuous(total, max_moves=max_moves, check_every=8)
+        hist = engine.play_continuous(total, max_moves=max_moves)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         searched = hist.metadata['moves_played'] * G * N
         stored = int(hist.lengths.sum().item())
