@@ -130,6 +130,102 @@ void run(const char* what, const float4* wts, const float4* rows, float* out, un
     fflush(stdout);
 }
 
+
+// The same stage with four wavefronts per workgroup, each owning 32 output columns of all 64 rows (one wavefront per
+// SIMD, twice the accumulators and weight fragments per wavefront): every wavefront still reads the whole tile, so the
+// LDS bytes per stage halve (4 x 32 KB) while the MFMA work per SIMD stays what it was.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void probe_wide(const float4* __restrict__ wts, int stages, float* out,
+                                                     unsigned long long* clocks) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2][64 * kLdW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < 2 * 64 * kLdW; i += 256) (&tile[0][0])[i] = (_Float16)(0.001f * (i & 63));
+    __syncthreads();
+    f32x4 acc[2][4], acx[2][4];
+    for (int c = 0; c < 2; ++c)
+        for (int m = 0; m < 4; ++m) acc[c][m] = acx[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bw[2][8];
+    const float4* wl = wts + wave * 128 + lane;
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < 8; ++j) bw[c][j] = wl[j * 512 + c * 64];
+    float4 af[2][4][2];
+    for (int m = 0; m < 4; ++m) af[0][m][0] = af[0][m][1] = af[1][m][0] = af[1][m][1] = make_float4(1e-3f, 2e-3f, 1e-3f, 0.f);
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+#pragma unroll 1
+    for (int st = 0; st < stages; ++st) {
+        const _Float16* ap = tile[st & 1] + n16 * kLdW + 8 * g;
+        const float4* wnext = wl + (size_t)((st + 1) & 15) * 4096;
+        if (MODE & 2) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+                af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if ((MODE & 2) && s + 1 < 4) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
+                    af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, bw[c][2 * s]), bl = __builtin_bit_cast(f16x8, bw[c][2 * s + 1]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, af[s & 1][m][0]), al = __builtin_bit_cast(f16x8, af[s & 1][m][1]);
+                    acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[c][m], 0, 0, 0);
+                    acx[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[c][m], 0, 0, 0);
+                    acx[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[c][m], 0, 0, 0);
+                }
+            }
+            if (MODE & 4) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    bw[c][2 * s] = wnext[(2 * s) * 512 + c * 64];
+                    bw[c][2 * s + 1] = wnext[(2 * s + 1) * 512 + c * 64];
+                }
+            }
+            if ((MODE & 2) && s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            if (MODE & 4) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sum = 0.f;
+    for (int c = 0; c < 2; ++c)
+        for (int m = 0; m < 4; ++m) sum += acc[c][m][0] + acc[c][m][1] + acc[c][m][2] + acc[c][m][3] + acx[c][m][0] + acx[c][m][1] + acx[c][m][2] + acx[c][m][3];
+    out[(size_t)blockIdx.x * 256 + tid] = sum;
+    if (lane == 0) {
+        clocks[((size_t)blockIdx.x * 4 + wave) * 2] = t1 - t0;
+        clocks[((size_t)blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int MODE>
+void run_wide(const char* what, const float4* wts, float* out, unsigned long long* clocks, int grid) {
+    const int stages = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    probe_wide<MODE><<<grid, 256>>>(wts, stages, out, clocks);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe_wide<MODE><<<grid, 256>>>(wts, stages, out, clocks);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)grid * 4 * stages * 96.0 * 16384.0;
+    printf("%-34s 4 waves x 32 columns: %8.3f ms = %6.0f ns per stage  %7.1f TFLOP/s f16 executed\n", what, ms,
+           ms * 1e6 / stages, flops / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 int main() {
     float4* wts;
     float* out;
@@ -151,6 +247,9 @@ int main() {
     run<5, 512>("MFMA + weight loads", wts, rows, out, clocks, grid);
     run<7, 256>("MFMA + LDS reads + weight loads", wts, rows, out, clocks, grid);
     run<7, 512>("MFMA + LDS reads + weight loads", wts, rows, out, clocks, grid);
+    run_wide<1>("MFMA only", wts, out, clocks, grid);
+    run_wide<3>("MFMA + LDS reads", wts, out, clocks, grid);
+    run_wide<7>("MFMA + LDS reads + weight loads", wts, out, clocks, grid);
     run<8, 512>("gather + barrier only", wts, rows, out, clocks, grid);
     run<12, 512>("weights + gather", wts, rows, out, clocks, grid);
     run<15, 512>("everything + gather + barrier", wts, rows, out, clocks, grid);
