@@ -33,6 +33,58 @@ def shard_bounds(total_games: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class DuckNetwork:
+    """Any object with the reference's network interface -- initial_inference(observation) and
+    recurrent_inference(hidden_state, action) returning an object with batch_hidden_state / batch_reward / batch_value /
+    batch_policy_logits (+ the to_scalar functions), agent.py:141, network.py:149-174 -- behind the two *_pool methods
+    the batched search calls.  The network is handed torch tensors on the search's device (observation [T, *shape] f32,
+    hidden_state [T, ...], action [T] i64) and may return torch tensors, numpy arrays or objects with .numpy(); hidden
+    states of any shape are kept in a [N+1, T, ...] tensor created at the first call.  The tree still runs on the GPU
+    pool; only the kernels of muzero_amd.network.Network are bypassed."""
+
+    def __init__(self, network, config, device):
+        self.net, self.config, self.device = network, config, torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.ACTION_SPACE_SIZE = config.game_config.action_space_size
+        self.observation_shape = getattr(network, 'OBSERVATION_SHAPE', None)
+        self.pool_hidden = None
+
+    def training_steps(self):
+        return self.net.training_steps()
+
+    def _tensor(self, x, dtype=torch.float32):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(x.numpy() if hasattr(x, 'numpy') else x)
+        return x.to(device=self.device, dtype=dtype)
+
+    def _scalars(self, out, which):
+        fused = getattr(out, f'batch_{which}_scalar', None)
+        raw = fused if fused is not None else getattr(out, f'{which}_to_scalar')(getattr(out, f'batch_{which}'))
+        return self._tensor(raw).reshape(-1)
+
+    def initial_inference_pool(self, observation, num_blocks, value, logits):
+        T = observation.shape[0]
+        obs = observation if self.observation_shape is None else observation.reshape(T, *self.observation_shape)
+        out = self.net.initial_inference(obs)
+        h = self._tensor(out.batch_hidden_state)
+        if self.pool_hidden is None or tuple(self.pool_hidden.shape[1:]) != tuple(h.shape) or self.pool_hidden.shape[0] != num_blocks:
+            self.pool_hidden = torch.empty(num_blocks, *h.shape, dtype=torch.float32, device=self.device)
+        self.pool_hidden[0].copy_(h)
+        value.copy_(self._scalars(out, 'value'))
+        logits.copy_(self._tensor(out.batch_policy_logits).reshape(T, self.ACTION_SPACE_SIZE))
+
+    def recurrent_inference_pool(self, parent_block, action, out_block, reward, value, logits):
+        T = parent_block.shape[0]
+        rows = torch.arange(T, device=self.device)
+        h = self.pool_hidden[parent_block.long().clamp(min=0), rows]          # leaf.parent.hidden_state (agent.py:204)
+        out = self.net.recurrent_inference(h, action.long().clamp(min=0))
+        self.pool_hidden[out_block].copy_(self._tensor(out.batch_hidden_state))
+        reward.copy_(self._scalars(out, 'reward'))
+        value.copy_(self._scalars(out, 'value'))
+        logits.copy_(self._tensor(out.batch_policy_logits).reshape(T, self.ACTION_SPACE_SIZE))
+
+
 class LockstepSearch:
     def __init__(self, config, network, num_trees: int, device=None, out=None, lanes_per_tree: int = 0):
         """`out`: optional (visits, root_value, minmax, policy, action) tensors to write the results to (views of a
@@ -41,16 +93,23 @@ class LockstepSearch:
         self.network = network
         g, m = config.game_config, config.mcts_config
         kb = config.value_config.known_bounds
+        self.native = isinstance(network, Network)
+        if not self.native:              # a duck-typed network (agent.py:141): the tree on the GPU, the network its own
+            if device is None and not hasattr(network, 'device'):
+                device = torch.device('cuda', torch.cuda.current_device())
+            self.duck = DuckNetwork(network, config, device if device is not None else network.device)
         self.device = torch.device(device) if device is not None else network.device
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.T, self.A, self.N = int(num_trees), g.action_space_size, m.num_simulations
-        if network.ACTION_SPACE_SIZE != self.A:
+        if self.native and network.ACTION_SPACE_SIZE != self.A:
             raise MuZeroError(f'network has {network.ACTION_SPACE_SIZE} actions, the game {self.A}')
         self.pool = TreePool(num_trees=self.T, num_actions=self.A, max_simulations=self.N,
                              num_players=g.num_players, discount=g.discount, default_value=m.default_value,
                              known_bounds=None if kb is None else kb.endpoints(), device=self.device,
                              lanes_per_tree=lanes_per_tree)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.hidden = torch.empty(self.N + 1, self.T, network.hidden_size, **f32)
+        self.hidden = torch.empty(self.N + 1, self.T, network.hidden_size, **f32) if self.native else None
         self.root_value_net = torch.empty(self.T, **f32)        # initial-inference value (unused by the search)
         self.logits = torch.empty(self.T, self.A, **f32)
         self.reward = torch.empty(self.T, **f32)
@@ -67,7 +126,6 @@ class LockstepSearch:
         _check_tensor('out minmax', self.out_minmax, torch.float64, (self.T, 2), self.device)
         _check_tensor('out policy', self.out_policy, torch.float32, (self.T, self.A), self.device)
         _check_tensor('out action', self.out_action, torch.int32, (self.T,), self.device)
-        self.native = isinstance(network, Network)
 
     def run_native(self, observation, noise, u, temperature, legal=None, n_legal=None, events=None, trace=None):
         """The whole move enqueued by one C call (mz_search_move): same launches as run(), no interpreter time
@@ -113,6 +171,8 @@ class LockstepSearch:
             return self.run_native(observation, noise, u, temperature, legal, n_legal)
         pool, net, N = self.pool, self.network, self.N
         pool.reset()
+        if not self.native:
+            return self._run_duck(observation, noise, u, temperature, legal, n_legal, hooks)
         net.initial_inference_pool(observation, self.hidden, self.root_value_net, self.logits)
         pool.expand_roots(self.logits, legal, n_legal, logits=True)
         pool.add_root_noise(noise, self.frac)
@@ -132,6 +192,28 @@ class LockstepSearch:
         visits, root_value, minmax, policy = pool.root_stats()
         chosen = pool.select_action(u, temperature)
         return visits, root_value, minmax, policy, chosen
+
+
+    def _run_duck(self, observation, noise, u, temperature, legal, n_legal, hooks):
+        pool, net, N = self.pool, self.duck, self.N
+        net.initial_inference_pool(observation, N + 1, self.root_value_net, self.logits)
+        pool.expand_roots(self.logits, legal, n_legal, logits=True)
+        pool.add_root_noise(noise, self.frac)
+        parent, action = pool.select()
+        for s in range(N):
+            if hooks is not None:
+                hooks.before_inference(s)
+            net.recurrent_inference_pool(parent, action, s + 1, self.reward, self.value, self.logits)
+            if hooks is not None:
+                hooks.after_inference(s)
+            if s + 1 < N:
+                parent, action = pool.step(self.logits, self.reward, self.value, logits=True)
+            else:
+                pool.expand_backprop(self.logits, self.reward, self.value, logits=True)
+            if hooks is not None:
+                hooks.after_tree(s)
+        visits, root_value, minmax, policy = pool.root_stats()
+        return visits, root_value, minmax, policy, pool.select_action(u, temperature)
 
 
 class PipelinedSearch:

@@ -118,6 +118,86 @@ def test_lockstep_search_with_network_in_the_loop(game):
     np.testing.assert_array_equal(chosen.cpu().numpy(), opool.select_action(u, 1.0))
 
 
+def test_lockstep_search_with_a_duck_typed_network():
+    """LockstepSearch with any object that has the reference's network interface (agent.py:141; here the numpy oracle
+    behind initial_inference / recurrent_inference): the tree runs on the GPU pool, the network is called once per
+    simulation with the gathered parent hidden states.  The outputs the tree consumed are the network's own, and the
+    search replays exactly through the C oracle."""
+    import torch
+    from muzero_amd.games import tictactoe
+    from muzero_amd.network import BatchNetworkOutput
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import c_oracle, net_oracle
+    N, T, A = 10, 50, 9
+    config = tictactoe.make_config(num_simulations=N)
+    ref = net_oracle.make_oracle('tictactoe', net_oracle.random_weights('tictactoe', 4))
+    ident = lambda x: x
+
+    class OracleNetwork:                       # knows nothing of muzero_amd.network.Network
+        calls = 0
+
+        def training_steps(self):
+            return 0
+
+        def initial_inference(self, observation):
+            h, v, logits, _ = ref.initial_inference(observation.cpu().numpy().reshape(-1, 27))
+            return BatchNetworkOutput(h.astype(np.float32), None, v.astype(np.float32), logits.astype(np.float32), ident, ident)
+
+        def recurrent_inference(self, hidden_state, action):
+            OracleNetwork.calls += 1
+            h, r, v, logits, _ = ref.recurrent_inference(hidden_state.cpu().numpy().astype(np.float64), action.cpu().numpy())
+            return BatchNetworkOutput(h.astype(np.float32), r.astype(np.float32), v.astype(np.float32),
+                                      logits.astype(np.float32), ident, ident)
+
+    rng = np.random.default_rng(8)
+    obs = rng.integers(0, 2, size=(T, 27)).astype(np.float32)
+    n_legal = rng.integers(0, A + 1, size=T).astype(np.int32)
+    n_legal[0] = A
+    legal = np.zeros((T, A), np.int32)
+    noise = np.zeros((T, A))
+    for t in range(T):
+        legal[t, :n_legal[t]] = np.sort(rng.permutation(A)[:n_legal[t]])
+        if n_legal[t]:
+            noise[t, :n_legal[t]] = rng.dirichlet([1.0] * int(n_legal[t]))
+    u = rng.random(T)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    search = LockstepSearch(config, OracleNetwork(), num_trees=T, device='cuda')
+    rec = Recorder(search)
+    visits, root_value, minmax, policy, chosen = search.run(dev(obs), dev(noise), dev(u), dev(np.ones(T)), dev(legal),
+                                                            dev(n_legal), hooks=rec)
+    assert OracleNetwork.calls == N
+    live = n_legal > 0
+    rows = np.nonzero(live)[0]
+    hidden = search.duck.pool_hidden.cpu().numpy()
+    for s in range(N):                         # the network saw leaf.parent.hidden_state and its outputs reached the tree
+        pb, act = rec.parent[s].cpu().numpy(), rec.action[s].cpu().numpy()
+        h2, r2, v2, l2, _ = ref.recurrent_inference(hidden[pb[live], rows].astype(np.float64), act[live])
+        np.testing.assert_array_equal(hidden[s + 1][live], h2.astype(np.float32))
+        np.testing.assert_array_equal(rec.reward[s].cpu().numpy()[live], r2.astype(np.float32))
+        np.testing.assert_array_equal(rec.logits[s].cpu().numpy()[live], l2.astype(np.float32))
+    kb = config.value_config.known_bounds
+    opool = c_oracle.OraclePool(T, A, N, config.game_config.num_players, config.game_config.discount,
+                                config.mcts_config.default_value, None if kb is None else kb.endpoints())
+    priors = np.zeros((N + 1, T, A), np.float32)
+    root = np.zeros((T, A), np.float32)
+    for t in rows:
+        p = search.pool.read_root_priors(int(t))
+        root[t, :len(p)] = p
+        for e in range(1, N + 1):
+            priors[e, t] = search.pool.read_block(int(t), e)['prior']
+    opool.expand_roots(root, legal, n_legal)
+    opool.add_root_noise(noise, config.mcts_config.root_exploration_fraction)
+    for s in range(N):
+        p, a = opool.select()
+        np.testing.assert_array_equal(p, rec.parent[s].cpu().numpy(), err_msg=f'parent block, simulation {s}')
+        np.testing.assert_array_equal(a, rec.action[s].cpu().numpy(), err_msg=f'action, simulation {s}')
+        opool.expand_backprop(priors[s + 1], rec.reward[s].cpu().numpy(), rec.value[s].cpu().numpy())
+    v2, rv2, mm2, pol2 = opool.root_stats()
+    np.testing.assert_array_equal(visits.cpu().numpy(), v2)
+    np.testing.assert_array_equal(root_value.cpu().numpy()[live], rv2[live])
+    np.testing.assert_array_equal(chosen.cpu().numpy(), opool.select_action(u, 1.0))
+
+
 def test_search_move_rejects_io_that_does_not_match_the_handles():
     """mz_search_move checks mz_move_io_t against the pool and the network before anything is launched."""
     import ctypes
