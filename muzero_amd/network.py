@@ -88,6 +88,35 @@ class BatchNetworkOutput:
                 for i in range(len(values))]
 
 
+# ---- state-action encoders (network.py:14-116) as tensor ops, for networks composed outside the built-in kernels
+# (the three built-in networks fold their encoder into a bias table or vector).  Tensors stay on
+# the device they are on.
+def one_hot_tensor_encoder(hidden_state: torch.Tensor, action: torch.Tensor, action_space_size: int) -> torch.Tensor:
+    """network.py:14-40: [B, ..., C] -> [B, ..., C + A]; channel C + action[b] is 1 at every position of sample b."""
+    planes = torch.zeros(hidden_state.shape[:-1] + (int(action_space_size),), dtype=hidden_state.dtype,
+                         device=hidden_state.device)
+    idx = action.to(device=hidden_state.device, dtype=torch.long).reshape((-1,) + (1,) * (hidden_state.dim() - 1))
+    planes.scatter_(-1, idx.expand(hidden_state.shape[:-1] + (1,)), 1.0)
+    return torch.cat([hidden_state, planes], dim=-1)
+
+
+def tensor_product_encoder(hidden_state: torch.Tensor, action: torch.Tensor, action_space_size: int) -> torch.Tensor:
+    """network.py:43-75: output[b, action[b], ...] = hidden_state[b, ...], zeros elsewhere ([B, A, ...])."""
+    B = hidden_state.shape[0]
+    out = torch.zeros((B, int(action_space_size)) + tuple(hidden_state.shape[1:]), dtype=hidden_state.dtype,
+                      device=hidden_state.device)
+    out[torch.arange(B, device=hidden_state.device), action.to(device=hidden_state.device, dtype=torch.long)] = hidden_state
+    return out
+
+
+def binary_plane_encoder(hidden_state: torch.Tensor, action: torch.Tensor, axis: int = 0) -> torch.Tensor:
+    """network.py:88-104: one more plane along `axis` (of a sample; +1 for the batch axis), all 0 or all 1 = action[b]."""
+    shape = list(hidden_state.shape)
+    shape[axis + 1] = 1
+    plane = action.to(device=hidden_state.device, dtype=hidden_state.dtype).reshape((-1,) + (1,) * (hidden_state.dim() - 1))
+    return torch.cat([hidden_state, plane.expand(shape)], dim=axis + 1)
+
+
 def glorot_uniform_weights(spec, seed: int) -> np.ndarray:
     """Keras defaults (glorot-uniform kernels, zero biases) for a [(name, shape)] spec -> flat float32."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -70,3 +70,25 @@ def test_network_shapes_and_parameter_counts():
     net = no.make_oracle('cartpole', no.random_weights('cartpole', 1))
     _, v, _, raw = net.initial_inference(np.array([[0.1, -0.2, 0.05, 0.3]], np.float32))
     assert raw.shape == (1, 101) and abs(raw.sum() - 1) < 1e-12 and 0 <= v[0] <= 100
+
+
+def test_product_encoders_match_the_reference_known_answer_and_the_oracle():
+    """muzero_amd.network's tensor-op encoders: the reference's known-answer test (network.py:77-85) and the numpy oracle
+    on random inputs (CPU tensors here; the ops are device-agnostic)."""
+    from muzero_amd import network as mn
+    states = torch.stack([k * torch.eye(2) for k in (1, 2, 3, 4)])
+    actions = torch.tensor([0, 2, 1, 2])
+    i, z = torch.eye(2), torch.zeros(2, 2)
+    answer = torch.stack([torch.stack(r) for r in ([i, z, z], [z, z, 2 * i], [z, 3 * i, z], [z, z, 4 * i])])
+    assert torch.norm(answer - mn.tensor_product_encoder(states, actions, 3)) < 1e-7
+    rng = np.random.default_rng(1)
+    h = rng.standard_normal((5, 3, 3, 4)).astype(np.float32)
+    a = rng.integers(0, 6, size=5)
+    np.testing.assert_array_equal(mn.one_hot_tensor_encoder(torch.from_numpy(h), torch.from_numpy(a), 6).numpy(),
+                                  no.one_hot_tensor_encoder(h, a, 6))
+    np.testing.assert_array_equal(mn.tensor_product_encoder(torch.from_numpy(h), torch.from_numpy(a), 6).numpy(),
+                                  no.tensor_product_encoder(h, a, 6))
+    b = rng.integers(0, 2, size=5)
+    for axis in (0, 1, 2):
+        np.testing.assert_array_equal(mn.binary_plane_encoder(torch.from_numpy(h), torch.from_numpy(b), axis).numpy(),
+                                      no.binary_plane_encoder(h, b, axis=axis))
