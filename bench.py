@@ -261,13 +261,20 @@ class NetworkMove:
         else:
             span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
             self.obs = ((torch.rand(T, 4, generator=g, device=device) * 2 - 1) * span).contiguous()
-            # batches <= 8192: network and tree step of 16 games fused in one kernel (cartpole16_step_kernel)
-            self.dominant = 'cartpole16_step_kernel' if T <= 8192 else 'cartpole_kernel<false'
+            # batches <= 8192: the N simulations of a move (network and tree step of 16 games per workgroup) are ONE
+            # launch, cartpole16_run_kernel (mz_infer_recurrent_run)
+            self.dominant = 'cartpole16_run_kernel' if T <= 8192 else 'cartpole_kernel<false'
             self.flops_per_eval = 223232
         self.noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).to(device).contiguous()
         self.u = torch.rand(T, generator=g, device=device, dtype=torch.float64)
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
         self.hooks = MoveEvents(wl['N'], event_stride)
+        self.evals_per_launch = self.trees_per_launch
+        if self.dominant == 'cartpole16_run_kernel':
+            # mz_search_move records the first sampled simulation's events around the whole run: one launch = N evaluations
+            # of every game
+            self.hooks.sampled = self.hooks.sampled[:1]
+            self.evals_per_launch = self.trees_per_launch * wl['N']
         self.gather = TrajectoryGather(T, A, device) if world > 1 else None
 
     def run(self, timed_events=False):
@@ -449,7 +456,7 @@ def main():
     split_f16 = with_net and not (wl['net'] == 'cartpole' and wl['T'] > 8192)
     if with_net:
         k1, rest = move.hooks.durations()
-        flops_launch = move.trees_per_launch * move.flops_per_eval
+        flops_launch = move.evals_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
         traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
                                 else (None, None))
@@ -466,7 +473,10 @@ def main():
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
                     'executed_mfma_tflops': executed, 'executed_frac': executed / peak}
         rest_name = ('head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else
-                     'after_fused_kernel_us' if move.dominant == 'cartpole16_step_kernel' else 'tree_step_kernel_us')
+                     'after_fused_kernel_us' if move.dominant == 'cartpole16_run_kernel' else 'tree_step_kernel_us')
+        if move.dominant == 'cartpole16_run_kernel':
+            roofline['simulations_per_launch'] = wl['N']
+            roofline['us_per_simulation'] = k1 * 1e6 / wl['N']
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         if rest_name == 'tree_step_kernel_us':       # the tree step is a launch of its own: its HBM roofline beside it

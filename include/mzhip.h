@@ -251,6 +251,23 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
                             int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,
                             float* out_reward, float* out_value, float* out_logits);
 
+/* run_mcts (reference agent.py:198-211) for all T trees of `pool`: `num_simulations` times { recurrent inference of the
+ * selected leaves' parents -> expand_node -> backpropagate -> select_leaf of the next simulation }, i.e. that many
+ * mz_infer_recurrent_step calls with with_select = 1, the last one with with_select = final_select.  The pool must hold a
+ * pending selection in parent_block / action (mz_select or a step with select).  Simulation i writes the hidden rows of
+ * the record it creates, block b = (simulations done so far) + 1 + i, to hidden_base + b * block_stride, and its outputs to
+ * out_reward / out_value + i * out_stride and out_logits + i * out_stride * A (out_stride = 0: every simulation overwrites
+ * the same T rows; else >= T).  trace_parent / trace_action (both or neither, [num_simulations][T]) receive the selection
+ * each simulation started from.  Same results as the separate calls.  For the CartPole network (pools of <= 8192 trees
+ * with the default lanes per tree) the whole run is ONE launch: a workgroup keeps its 16 games from the first simulation to
+ * the last, so no launch boundary, no host call and no other workgroup's data separates two simulations; other networks
+ * and pools run it as the sequence of mz_infer_recurrent_step launches.  net and pool must use the same device and
+ * stream. */
+int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
+                           float* hidden_base, int32_t* parent_block, int64_t block_stride, int32_t* action,
+                           float* out_reward, float* out_value, float* out_logits, int64_t out_stride,
+                           int32_t* trace_parent, int32_t* trace_action);
+
 /* ---- one move of T games, enqueued natively (batched MCTSAgent.make_move, reference agent.py:219-232) ------- */
 
 typedef struct mz_move_io {

@@ -94,6 +94,8 @@ PROTOTYPES = {
     'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_infer_recurrent_step': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mz_infer_recurrent_run': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'mz_search_move': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(MoveIO)]),
     'mz_search_move_injected': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p]),

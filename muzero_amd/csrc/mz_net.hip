@@ -1161,6 +1161,31 @@ __device__ __forceinline__ f32x4 mma16(const _Float16* sA, const BFrag16& b, int
     }
     return acc + (acx0 + acx1) * kUnsplit;
 }
+// the same for two 16-column blocks of one wave (b[0], b[1]), the activation fragments read once
+__device__ __forceinline__ void mma16x2(const _Float16* sA, const BFrag16 (&b)[2], int lane, f32x4 (&out)[2]) {
+    const _Float16* ap = sA + (lane & 15) * kLdW + 8 * (lane >> 4);
+    float4 a[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
+        a[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
+    }
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2] = {z, z}, acx0[2] = {z, z}, acx1[2] = {z, z};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, a[s][0]), al = __builtin_bit_cast(f16x8, a[s][1]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, b[c].v[2 * s]), bl = __builtin_bit_cast(f16x8, b[c].v[2 * s + 1]);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[c], 0, 0, 0);
+            acx0[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx0[c], 0, 0, 0);
+            acx1[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx1[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) out[c] = acc[c] + (acx0[c] + acx1[c]) * kUnsplit;
+}
 // sum over the four lanes n16 + 16 g of a game (the wave's sixteen columns); every lane gets it
 __device__ __forceinline__ float sum_over_g(float x) {
     const unsigned u = __float_as_uint(x);
@@ -1182,7 +1207,8 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
                                                 int* parent_block, long block_stride, int* action,
                                                 float* __restrict__ out_hidden, float* __restrict__ out_reward,
                                                 float* __restrict__ out_value, float* __restrict__ out_logits,
-                                                float* __restrict__ out_value_raw, const PoolDev& p, int nb) {
+                                                float* __restrict__ out_value_raw, const PoolDev& p, int nb,
+                                                bool do_select = true) {
     constexpr int ROWS = 16;
     constexpr int G = 2, PB = TreeLds<G>::kPB;
     __shared__ __attribute__((aligned(16))) float sTreeRows[FUSE ? ROWS * TreeLds<G>::kRow : 4];
@@ -1403,7 +1429,7 @@ __device__ __forceinline__ void cartpole16_body(const CartDev& w, int B, const f
             const float* mine = sOut[tid < ROWS * G ? tid / G : 0];
             float* lds_row = sTreeRows + (tid < ROWS * G ? tid / G : 0) * TreeLds<G>::kRow;
             backprop_tree<G, true, PB>(p, tree, tree_active, gl, nb, mine + 2, mine[0], mine[1], pf, lds_row);
-            if (FUSE == 2) {
+            if (FUSE == 2 && do_select) {
                 // a tree's two lanes lie inside this wavefront, whose vector memory operations are performed in program
                 // order: compiler ordering is enough (step_kernel, mz_tree.hip)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1435,6 +1461,395 @@ __global__ __launch_bounds__(kThreads16) void cartpole16_step_kernel(CartDev w, 
                                                                      float* __restrict__ out_logits) {
     cartpole16_body<false, SELECT ? 2 : 1>(w, p.T, in_base, parent_block, block_stride, action, out_hidden, out_reward,
                                            out_value, out_logits, nullptr, p, nb);
+}
+
+// run_mcts (agent.py:198-211) of 16 games in ONE launch: `nsim` simulations -- recurrent inference, expand_node,
+// backpropagate, select_leaf of the next one -- looped inside the kernel.  A workgroup owns its 16 games from the first
+// simulation to the last, so nothing crosses workgroups and nothing a simulation needs waits for a launch:
+//   * the 16 trees live in LDS for the whole run (records packed to 80 bytes: Slot[2] + BackSlot[2]; per-tree root
+//     statistics, min/max, path; the log table): copied in at the start, copied back to the pool at the end.  The tree
+//     code is mz_tree_dev.h's, unchanged, run on a PoolDev whose pointers address the LDS copy -- a descent level costs
+//     an LDS round trip instead of an L2 one;
+//   * the weights of the first four stages (conv, dense, reward dense, prediction dense 1: 128 registers a lane) stay
+//     in registers across all simulations; the last two stages' stream in while the first four compute;
+//   * biases and head weights sit in LDS; the hidden rows a simulation gathers were written by this workgroup
+//     (workgroup-scope release / acquire of __syncthreads).
+// Simulation i takes record nb0 + i and writes hidden block nb0 + i; its outputs go to out_* + i * out_stride rows
+// (out_stride = 0: every simulation overwrites the same T rows), its selection to trace_parent / trace_action [i][T] when
+// those are set.  The last simulation selects only if `final_select`.  Same arithmetic, stage by stage, as
+// cartpole16_body: same results.
+// All-lanes reduction over the 16 lanes of a DPP row with a commutative operator: the xor-butterfly's operand pairs
+// (steps 1 and 2 quad permutes; 4 and 8 the half-row / row mirrors, which pair the same values once quads / half rows are
+// uniform), hence the bits of the __shfl_xor loop, without its four LDS-crossbar round trips.
+template <typename Op>
+__device__ __forceinline__ float row16_allreduce(float x, Op op) {
+    x = op(x, dpp_f32<kDppXor1>(x));
+    x = op(x, dpp_f32<kDppXor2>(x));
+    x = op(x, dpp_f32<kDppHalfMirror>(x));
+    x = op(x, dpp_f32<kDppMirror>(x));
+    return x;
+}
+// workgroup barrier that orders LDS only: a wave's outstanding global stores are not waited for (__syncthreads does)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+constexpr int kCartRunRS = 80, kCartRunOffBack = 48;
+struct CartRunLayout {          // byte offsets inside the dynamic LDS block
+    int recs, root_prior, root_vsum, mm_min, mm_max, sum_len, sims, path, log, ints, total;
+};
+__host__ __device__ inline CartRunLayout cart_run_layout(int nrec, int N) {
+    CartRunLayout L;
+    int o = 0;
+    L.recs = o;        o += 16 * nrec * kCartRunRS;
+    L.root_prior = o;  o += 16 * 2 * 8;
+    L.root_vsum = o;   o += 16 * 8;
+    L.mm_min = o;      o += 16 * 8;
+    L.mm_max = o;      o += 16 * 8;
+    L.sum_len = o;     o += 16 * 8;
+    L.sims = o;        o += 16 * 8;
+    L.path = o;        o += 16 * (N + 1) * 8;
+    L.log = o;         o += (N + 2) * 8;
+    L.ints = o;        o += 5 * 16 * 4;          // n_root, root_count, path_len, parent, action
+    L.total = (o + 15) & ~15;
+    return L;
+}
+constexpr int kCartRunMaxDynLds = 120 * 1024;    // beside ~36 KB of static LDS
+
+constexpr int kRunThreads = 256;      // four wavefronts, one per SIMD: 512 registers a lane, 384 of them weights
+__global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, PoolDev p, int nb0, int nsim, int final_select,
+                                                                    float* hidden_base, int* parent_block, long block_stride,
+                                                                    int* action, float* out_reward, float* out_value,
+                                                                    float* out_logits, long out_stride, int* trace_parent,
+                                                                    int* trace_action) {
+    constexpr int ROWS = 16;
+    constexpr int G = 2, PB = TreeLds<G>::kPB;
+    extern __shared__ __attribute__((aligned(16))) char sTree[];
+    __shared__ __attribute__((aligned(16))) float sTreeRows[ROWS * TreeLds<G>::kRow];
+    __shared__ float sOut[ROWS][4];                  // reward, value, the two logits: the tree step's inputs
+    __shared__ __attribute__((aligned(16))) _Float16 sBuf[2][ROWS * kLdW];      // split activation tiles
+    __shared__ __attribute__((aligned(16))) float sV[ROWS * kLd];                // the 101 value logits, f32
+    __shared__ float sPart[3][8][ROWS];              // reward / policy 0 / policy 1 partial dots of the eight waves
+    __shared__ long sRowOff[ROWS];
+    __shared__ float sAct[ROWS];
+    // rows: 0 conv bias, 1 action plane, 2 hidden dense bias, 3 reward dense bias, 4 reward weights, 5 / 6 prediction dense
+    // biases, 7 value bias, 8 / 9 policy weights
+    __shared__ __attribute__((aligned(16))) float sBias[10 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4;
+    const int lcol0 = wave * 32 + 4 * g;                 // this lane's four output columns of game n16 in the wave's first
+                                                         // 16-column block; the second block's are 16 further
+    const int row0 = blockIdx.x * ROWS;
+    const int nrec = nb0 + nsim;
+    const CartRunLayout L = cart_run_layout(nrec, p.N);
+    _Float16* sX = sBuf[0];
+    _Float16* sH = sBuf[1];
+
+    // ---- the pool as this workgroup sees it: 16 trees in LDS
+    PoolDev q = p;
+    q.T = ROWS;
+    q.RS = kCartRunRS;
+    q.off_back = kCartRunOffBack;
+    q.tree_stride = (size_t)nrec * kCartRunRS;
+    q.blocks = sTree + L.recs;
+    q.root_prior = reinterpret_cast<double*>(sTree + L.root_prior);
+    q.root_vsum = reinterpret_cast<double*>(sTree + L.root_vsum);
+    q.mm_min = reinterpret_cast<double*>(sTree + L.mm_min);
+    q.mm_max = reinterpret_cast<double*>(sTree + L.mm_max);
+    q.sum_len = reinterpret_cast<long long*>(sTree + L.sum_len);
+    q.sims = reinterpret_cast<long long*>(sTree + L.sims);
+    q.path = reinterpret_cast<int2*>(sTree + L.path);
+    int* sInts = reinterpret_cast<int*>(sTree + L.ints);
+    q.n_root = sInts;
+    q.root_count = sInts + 16;
+    q.path_len = sInts + 32;
+    int* sParent = sInts + 48;
+    int* sAction = sInts + 64;
+    double* sLog = reinterpret_cast<double*>(sTree + L.log);
+
+    // the weights, resident for the whole run: six stages x two 16-column blocks x 32 registers
+    BFrag16 wc[2], wd[2], wr[2], w1[2], w2[2], wv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        load_b16(wc[c], w.dyn_conv_s, lane, 2 * wave + c);
+        load_b16(wd[c], w.dyn_dense_s, lane, 2 * wave + c);
+        load_b16(wr[c], w.dyn_rdense_s, lane, 2 * wave + c);
+        load_b16(w1[c], w.pred_dense1_s, lane, 2 * wave + c);
+        load_b16(w2[c], w.pred_dense2_s, lane, 2 * wave + c);
+        load_b16(wv[c], w.pred_value_s, lane, 2 * wave + c);
+    }
+    {   // records [0, nb0) of the 16 trees, 16 bytes a thread and step; the records to come start zeroed
+        const int per_tree = nrec * 5;
+        for (int idx = tid; idx < ROWS * per_tree; idx += kRunThreads) {
+            const int t = idx / per_tree, rem = idx - t * per_tree, e = rem / 5, c = rem - e * 5;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + t < p.T && e < nb0)
+                v = *reinterpret_cast<const float4*>(rec(p, row0 + t, e) + (c < 3 ? c * 16 : p.off_back + (c - 3) * 16));
+            *reinterpret_cast<float4*>(sTree + L.recs + (size_t)t * q.tree_stride + e * kCartRunRS + c * 16) = v;
+        }
+        for (int idx = tid; idx < ROWS * (p.N + 1); idx += kRunThreads) {
+            const int t = idx / (p.N + 1), d = idx - t * (p.N + 1);
+            q.path[idx] = row0 + t < p.T ? p.path[(size_t)(row0 + t) * (p.N + 1) + d] : make_int2(0, 0);
+        }
+        for (int idx = tid; idx < p.N + 2; idx += kRunThreads) sLog[idx] = p.log_table[idx];
+        if (tid < ROWS) {
+            const int t = row0 + tid;
+            const bool in = t < p.T;
+            q.n_root[tid] = in ? p.n_root[t] : 0;
+            q.root_count[tid] = in ? p.root_count[t] : 0;
+            q.path_len[tid] = in ? p.path_len[t] : 0;
+            sParent[tid] = in ? parent_block[t] : -1;
+            sAction[tid] = in ? action[t] : -1;
+            q.root_vsum[tid] = in ? p.root_vsum[t] : 0.0;
+            q.mm_min[tid] = in ? p.mm_min[t] : 0.0;
+            q.mm_max[tid] = in ? p.mm_max[t] : 0.0;
+            q.root_prior[2 * tid] = in ? p.root_prior[(size_t)t * 2] : 0.0;
+            q.root_prior[2 * tid + 1] = in ? p.root_prior[(size_t)t * 2 + 1] : 0.0;
+            q.sum_len[tid] = 0;
+            q.sims[tid] = 0;
+        }
+        for (int idx = tid; idx < 10 * 128; idx += kRunThreads) {
+            const int r = idx >> 7, c = idx & 127;
+            const float* src = r == 0   ? w.dyn_conv_b
+                               : r == 1 ? w.dyn_plane
+                               : r == 2 ? w.dyn_dense_b
+                               : r == 3 ? w.dyn_rdense_b
+                               : r == 4 ? w.dyn_reward_w
+                               : r == 5 ? w.pred_dense1_b
+                               : r == 6 ? w.pred_dense2_b
+                               : r == 7 ? w.pred_value_b
+                                        : w.pred_policy_w + (r - 8) * 128;
+            sBias[idx] = src[c];
+        }
+    }
+    const float policy_b0 = w.pred_policy_b[0], policy_b1 = w.pred_policy_b[1];
+    __syncthreads();
+    MZ_TRACE_DECL;
+    MZ_TRACE(0);                                         // prologue: weights, trees and tables in place
+
+    // the tree step's lanes: wave 0, lanes 0..31 = 16 games x 2; the others come along inactive, outside every tree
+    const int ltree = tid < ROWS * G ? tid / G : ROWS, gl = tid % G;
+    const bool tree_active = tid < ROWS * G && row0 + ltree < p.T && q.n_root[ltree] > 0;
+    const LdsLog lds_log = (LdsLog)sLog;
+    float vmax = 0.f;
+    auto bias4 = [&](int r, int c) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0 + 16 * c); };
+    auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
+        v[0] = fmaxf(acc[0] + bias.x, 0.f);
+        v[1] = fmaxf(acc[1] + bias.y, 0.f);
+        v[2] = fmaxf(acc[2] + bias.z, 0.f);
+        v[3] = fmaxf(acc[3] + bias.w, 0.f);
+    };
+    auto store4 = [&](const float (&v)[4], _Float16* sOutT, int c) {
+        uint2 h, l;
+        split4(v, h, l, vmax);
+        *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + lcol0 + 16 * c) = h;
+        *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + 128 + lcol0 + 16 * c) = l;
+    };
+    auto dot4 = [&](const float (&v)[4], const float4& wv) {
+        return __builtin_fmaf(v[3], wv.w, __builtin_fmaf(v[2], wv.z, __builtin_fmaf(v[1], wv.y, v[0] * wv.x)));
+    };
+
+#pragma unroll 1
+    for (int i = 0; i < nsim; ++i) {
+        asm volatile("" ::: "memory");                   // nothing below is hoisted out of the loop (registers)
+        const int nb = nb0 + i;
+        const bool keep = out_stride != 0 || i + 1 == nsim;       // outputs no later simulation overwrites
+        if (tid < ROWS) {
+            const int b = row0 + tid;
+            const int pb = sParent[tid], a = sAction[tid];
+            long off = -1;
+            if (b < p.T && pb >= 0) off = (long)pb * block_stride + (long)b * 128;
+            sRowOff[tid] = off;
+            sAct[tid] = a == 1 ? 1.f : 0.f;
+            if (trace_parent != nullptr && b < p.T) {
+                trace_parent[(size_t)i * p.T + b] = pb;
+                trace_action[(size_t)i * p.T + b] = a;
+            }
+        }
+        lds_barrier();
+        const bool lrow_ok = sRowOff[n16] >= 0;
+        f32x4 acc[2];
+        float v[4];
+        // gather leaf.parent.hidden_state rows (agent.py:204) into LDS: 16 rows x 32 pieces of four floats
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + kRunThreads * j, r = idx >> 5, c4 = idx & 31;
+            const long off = sRowOff[r];
+            const float4 x = off >= 0 ? *reinterpret_cast<const float4*>(hidden_base + off + c4 * 4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+            uint2 h, l;
+            split4(xv, h, l, vmax);
+            *reinterpret_cast<uint2*>(sH + r * kLdW + c4 * 4) = h;
+            *reinterpret_cast<uint2*>(sH + r * kLdW + 128 + c4 * 4) = l;
+        }
+        lds_barrier();
+        MZ_TRACE(5);                                     // parent rows gathered
+        // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
+        mma16x2(sH, wc, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float a = sAct[n16];
+            const float4 bc = bias4(0, c), pl = bias4(1, c);
+            const float4 bca = make_float4(bc.x + a * pl.x, bc.y + a * pl.y, bc.z + a * pl.z, bc.w + a * pl.w);
+            act4(acc[c], bca, v);
+            store4(v, sX, c);
+        }
+        lds_barrier();
+        mma16x2(sX, wd, lane, acc);                                           // Dense relu = hidden' (:108)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            act4(acc[c], bias4(2, c), v);
+            store4(v, sH, c);                            // sH's previous contents (the gathered input) are no longer read
+            if (lrow_ok)
+                *reinterpret_cast<float4*>(hidden_base + (size_t)nb * block_stride + (size_t)(row0 + n16) * 128 + lcol0 +
+                                           16 * c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        lds_barrier();
+        // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114); the dot from the accumulators
+        mma16x2(sH, wr, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            act4(acc[c], bias4(3, c), v);
+            const float part = sum_over_g(dot4(v, bias4(4, c)));
+            if (g == 0) sPart[0][2 * wave + c][n16] = part;
+        }
+        // prediction: Dense relu, Dense relu (games/cartpole.py:121-124)
+        mma16x2(sH, w1, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            act4(acc[c], bias4(5, c), v);
+            store4(v, sX, c);
+        }
+        lds_barrier();                                     // sX complete, sH no longer read, sPart[0] complete
+        MZ_TRACE(6);                                     // four stages
+        if (tid < ROWS && sRowOff[tid] >= 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += sPart[0][k][tid];
+            const float r = 1.f / (1.f + expf(-(s + w.dyn_reward_b)));
+            if (keep) out_reward[(size_t)i * out_stride + row0 + tid] = r;
+            sOut[tid][0] = r;
+        }
+        mma16x2(sX, w2, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            act4(acc[c], bias4(6, c), v);
+            store4(v, sH, c);
+            // policy logits: Dense 2 (:127), from the accumulators
+            const float p0 = sum_over_g(dot4(v, bias4(8, c))), p1 = sum_over_g(dot4(v, bias4(9, c)));
+            if (g == 0) {
+                sPart[1][2 * wave + c][n16] = p0;
+                sPart[2][2 * wave + c][n16] = p1;
+            }
+        }
+        lds_barrier();
+        // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
+        mma16x2(sH, wv, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 bv = bias4(7, c);
+            *reinterpret_cast<float4*>(sV + n16 * kLd + lcol0 + 16 * c) =
+                make_float4(acc[c][0] + bv.x, acc[c][1] + bv.y, acc[c][2] + bv.z, acc[c][3] + bv.w);
+        }
+        lds_barrier();
+        MZ_TRACE(7);                                     // two stages
+        const int row = (tid >> 4) & 15, qq = tid & 15, b = row0 + row;        // 16 threads per row (threads 0..255)
+        const bool rowthread = tid < ROWS * 16;
+        const bool live = rowthread && sRowOff[row] >= 0;
+        if (rowthread) {
+            // this thread's bins qq, qq + 16, ... (seven, the last one past the 101 for qq >= 5) in registers; the same
+            // operations in the same order as cartpole16_body's three passes over LDS
+            const float* z = sV + row * kLd;
+            float zz[7];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) zz[t] = z[min(qq + 16 * t, 100)];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                if (qq + 16 * t < 101) mx = fmaxf(mx, zz[t]);
+            mx = row16_allreduce(mx, [](float x, float y) { return fmaxf(x, y); });
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                if (qq + 16 * t < 101) {
+                    zz[t] = expf(zz[t] - mx);
+                    den += zz[t];
+                }
+            den = row16_allreduce(den, [](float x, float y) { return x + y; });
+            float y = 0.f;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                if (qq + 16 * t < 101) {
+                    const float pj = zz[t] / den;
+                    y += pj * (float)(qq + 16 * t);
+                }
+            y = row16_allreduce(y, [](float x, float y2) { return x + y2; });
+            if (qq == 0 && live) {
+                y = y / 100.f;
+                const float t = (sqrtf(2.f) - 1.f) * y + 1.f;
+                const float val = 0.f + (100.f - 0.f) * (t * t - 1.f);     // config.py:38-40 with bounds (0,100)
+                if (keep) out_value[(size_t)i * out_stride + b] = val;
+                sOut[row][1] = val;
+            }
+            if (qq < 2 && live) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += sPart[1 + qq][k][row];
+                const float logit = s + (qq == 0 ? policy_b0 : policy_b1);
+                if (keep) out_logits[((size_t)i * out_stride + b) * 2 + qq] = logit;
+                sOut[row][2 + qq] = logit;
+            }
+        }
+        lds_barrier();
+        MZ_TRACE(11);                                    // softmax, outputs
+        if (wave == 0) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
+            const int lt = tid < ROWS * G ? ltree : 0;
+            const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(q, lt, tid < ROWS * G, gl);
+            const float* mine = sOut[lt];
+            float* lds_row = sTreeRows + lt * TreeLds<G>::kRow;
+            backprop_tree<G, true, PB>(q, tid < ROWS * G ? ltree : q.T, tree_active, gl, nb, mine + 2, mine[0], mine[1], pf,
+                                       lds_row);
+            if (i + 1 < nsim || final_select != 0) {
+                // a tree's two lanes lie inside this wavefront, whose LDS operations are performed in program order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                select_tree<G>(q, tid < ROWS * G ? ltree : q.T, tree_active, gl, sParent, sAction, lds_log);
+            }
+        }
+        __syncthreads();                                 // also: this simulation's hidden rows are visible to the gathers to come
+    }
+    note_range(vmax, w.range_flag);
+
+    // ---- the trees go back to the pool
+    {
+        const int per_tree = nrec * 5;
+        for (int idx = tid; idx < ROWS * per_tree; idx += kRunThreads) {
+            const int t = idx / per_tree, rem = idx - t * per_tree, e = rem / 5, c = rem - e * 5;
+            if (row0 + t < p.T)
+                *reinterpret_cast<float4*>(rec(p, row0 + t, e) + (c < 3 ? c * 16 : p.off_back + (c - 3) * 16)) =
+                    *reinterpret_cast<const float4*>(sTree + L.recs + (size_t)t * q.tree_stride + e * kCartRunRS + c * 16);
+        }
+        for (int idx = tid; idx < ROWS * (p.N + 1); idx += kRunThreads) {
+            const int t = idx / (p.N + 1), d = idx - t * (p.N + 1);
+            if (row0 + t < p.T) p.path[(size_t)(row0 + t) * (p.N + 1) + d] = q.path[idx];
+        }
+        if (tid < ROWS && row0 + tid < p.T) {
+            const int t = row0 + tid;
+            p.root_count[t] = q.root_count[tid];
+            p.path_len[t] = q.path_len[tid];
+            p.root_vsum[t] = q.root_vsum[tid];
+            p.mm_min[t] = q.mm_min[tid];
+            p.mm_max[t] = q.mm_max[tid];
+            p.sum_len[t] += q.sum_len[tid];
+            p.sims[t] += q.sims[tid];
+            if (final_select != 0) {
+                parent_block[t] = sParent[tid];
+                action[t] = sAction[tid];
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------- Atari-shaped
@@ -2412,6 +2827,62 @@ __attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->h
 __attribute__((visibility("hidden"))) int mz_net_hidden_size_of(const mz_net* net) { return mz_net_hidden_size(net->kind); }
 __attribute__((visibility("hidden"))) int mz_net_num_actions_of(const mz_net* net) { return mz_net_num_actions(net->kind); }
 __attribute__((visibility("hidden"))) hipStream_t mz_net_stream_of(const mz_net* net) { return net->stream; }
+
+static bool run_fusable_cart(const mz_net* net, const mz_pool* pool) {
+    // the trees of a workgroup's 16 games must fit its LDS for a whole move (the pool's max_simulations + 1 records)
+    return net->kind == MZ_NET_CARTPOLE && pool->G == 2 && pool->dev.A == 2 && pool->dev.T <= kCart16MaxBatch &&
+           pool->dev.off_back % 16 == 0 && cart_run_layout(pool->dev.N + 1, pool->dev.N).total <= kCartRunMaxDynLds;
+}
+__attribute__((visibility("hidden"))) int mz_net_run_is_one_launch(const mz_net* net, const mz_pool* pool) {
+    return run_fusable_cart(net, pool) ? 1 : 0;
+}
+
+int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
+                           float* hidden_base, int32_t* parent_block, int64_t block_stride, int32_t* action,
+                           float* out_reward, float* out_value, float* out_logits, int64_t out_stride,
+                           int32_t* trace_parent, int32_t* trace_action) {
+    MZ_REQUIRE(net != nullptr && pool != nullptr, "net/pool is NULL");
+    MZ_REQUIRE(hidden_base && parent_block && action && out_reward && out_value && out_logits,
+               "hidden_base/parent_block/action/out_reward/out_value/out_logits is NULL");
+    MZ_REQUIRE(num_simulations >= 1, "num_simulations must be >= 1 (got %d)", num_simulations);
+    MZ_REQUIRE(block_stride >= (int64_t)pool->dev.T * mz_net_hidden_size(net->kind),
+               "block_stride must hold the hidden rows of all %d trees", pool->dev.T);
+    MZ_REQUIRE(out_stride == 0 || out_stride >= pool->dev.T, "out_stride must be 0 or >= the number of trees");
+    MZ_REQUIRE((trace_parent == nullptr) == (trace_action == nullptr), "trace_parent and trace_action go together");
+    MZ_REQUIRE(net->device == pool->device && net->stream == pool->stream, "net and pool must share device and stream");
+    const int T = pool->dev.T, A = pool->dev.A;
+    if (run_fusable_cart(net, pool)) {
+        int nb0 = 0;
+        int s = mz_pool_begin_run(pool, num_simulations, final_select != 0, &nb0);
+        if (s != MZ_OK) return s;
+        MZ_HIP(hipSetDevice(net->device));
+        const int dyn_lds = cart_run_layout(nb0 + num_simulations, pool->dev.N).total;
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cartpole16_run_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCartRunMaxDynLds));
+        cartpole16_run_kernel<<<(T + 15) / 16, kRunThreads, dyn_lds, net->stream>>>(
+            net->cart, pool->dev, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
+            out_reward, out_value, out_logits, (long)out_stride, trace_parent, trace_action);
+        s = launch_status("recurrent inference + tree step, all simulations");
+        if (s != MZ_OK) return s;
+        mz_pool_commit_run(pool, num_simulations, final_select != 0);
+        return MZ_OK;
+    }
+    for (int i = 0; i < num_simulations; ++i) {       // the same work, a simulation at a time
+        if (trace_parent) {
+            MZ_HIP(hipMemcpyAsync(trace_parent + (size_t)i * T, parent_block, (size_t)T * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, net->stream));
+            MZ_HIP(hipMemcpyAsync(trace_action + (size_t)i * T, action, (size_t)T * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, net->stream));
+        }
+        const int nb = pool->blocks_in_use;
+        const int s = mz_infer_recurrent_step(net, pool, (i + 1 < num_simulations || final_select) ? 1 : 0, hidden_base,
+                                              parent_block, block_stride, action, hidden_base + (size_t)nb * block_stride,
+                                              out_reward + (size_t)i * out_stride, out_value + (size_t)i * out_stride,
+                                              out_logits + (size_t)i * out_stride * A);
+        if (s != MZ_OK) return s;
+    }
+    return MZ_OK;
+}
 
 int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select, const float* hidden_base,
                             int32_t* parent_block, int64_t block_stride, int32_t* action, float* out_hidden,

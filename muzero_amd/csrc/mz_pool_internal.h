@@ -24,6 +24,11 @@ struct mz_pool {
 int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block);
 void mz_pool_commit_backprop(mz_pool* pool, bool with_select);
 
+// The same for `num_simulations` expand+backprops in one launch (mz_infer_recurrent_run), each but the last fused with
+// the next select, the last one too when `final_select`; returns the block of the first.
+int mz_pool_begin_run(mz_pool* pool, int num_simulations, bool final_select, int* out_first_block);
+void mz_pool_commit_run(mz_pool* pool, int num_simulations, bool final_select);
+
 // A native move (mz_search_move) brackets its inferences with these: begin = the initial inference (mz_infer_initial's
 // arguments; hidden_block0 receives the root hidden states), after which and until end the network keeps the move's
 // hidden workspace in an internal format (mz_net.hip).
@@ -36,6 +41,8 @@ extern "C" void mz_net_end_move(mz_net* net);
 extern "C" int mz_net_hidden_size_of(const mz_net* net);
 extern "C" int mz_net_num_actions_of(const mz_net* net);
 extern "C" hipStream_t mz_net_stream_of(const mz_net* net);
+// mz_infer_recurrent_run is one launch for this network and pool (else it loops over mz_infer_recurrent_step)
+extern "C" int mz_net_run_is_one_launch(const mz_net* net, const mz_pool* pool);
 
 // mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL), one launch
 extern "C" int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits, const int32_t* legal,

@@ -1,7 +1,7 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as 2N+5 HIP launches (TicTacToe; N+4 for CartPole) on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as 2N+5 HIP launches (TicTacToe; 5 for CartPole, whose N simulations are one launch) on one stream with no host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
@@ -46,26 +46,44 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
     MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
     MZ_TRY_(mz_expand_roots_noise(pool, io->logits, 1, io->legal, io->n_legal, io->noise, io->noise_frac));
     MZ_TRY_(mz_select(pool, io->parent_block, io->action));
-    for (int s = 0; s < N; ++s) {
-        const bool timed = ev && ev[4 * s];           // a simulation whose events are NULL is not timed
-        if (timed) {
-            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s]), static_cast<hipStream_t>(io->stream)));
-            MZ_TRY_(mz_net_set_mid_event(net, ev[4 * s + 1]));
-        } else if (ev) {
-            MZ_TRY_(mz_net_set_mid_event(net, nullptr));
+    if (!ev || mz_net_run_is_one_launch(net, pool)) {
+        // run_mcts as one call (one launch where the network and pool allow it).  Timing events then bracket the whole
+        // run: those of the first simulation that has any are recorded, [0] before it, [1] and [2] after it.
+        int s0 = -1;
+        for (int s = 0; ev && s < N && s0 < 0; ++s)
+            if (ev[4 * s]) s0 = s;
+        if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
+        if (s0 >= 0) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s0]), st));
+        MZ_TRY_(mz_infer_recurrent_run(net, pool, N, 0, io->hidden, io->parent_block, (int64_t)T * H, io->action,
+                                       trace ? io->trace_reward : io->reward, trace ? io->trace_value : io->value,
+                                       trace ? io->trace_logits : io->logits, trace ? (int64_t)T : 0,
+                                       trace ? io->trace_parent : nullptr, trace ? io->trace_action : nullptr));
+        if (s0 >= 0) {
+            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s0 + 1]), st));
+            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s0 + 2]), st));
         }
-        if (trace) {      // this simulation's selection, before the fused step overwrites it with the next one
-            MZ_HIP(hipMemcpyAsync(io->trace_parent + (size_t)s * T, io->parent_block, (size_t)T * sizeof(int32_t),
-                                  hipMemcpyDeviceToDevice, st));
-            MZ_HIP(hipMemcpyAsync(io->trace_action + (size_t)s * T, io->action, (size_t)T * sizeof(int32_t),
-                                  hipMemcpyDeviceToDevice, st));
+    } else {
+        for (int s = 0; s < N; ++s) {
+            const bool timed = ev && ev[4 * s];           // a simulation whose events are NULL is not timed
+            if (timed) {
+                MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s]), static_cast<hipStream_t>(io->stream)));
+                MZ_TRY_(mz_net_set_mid_event(net, ev[4 * s + 1]));
+            } else if (ev) {
+                MZ_TRY_(mz_net_set_mid_event(net, nullptr));
+            }
+            if (trace) {      // this simulation's selection, before the fused step overwrites it with the next one
+                MZ_HIP(hipMemcpyAsync(io->trace_parent + (size_t)s * T, io->parent_block, (size_t)T * sizeof(int32_t),
+                                      hipMemcpyDeviceToDevice, st));
+                MZ_HIP(hipMemcpyAsync(io->trace_action + (size_t)s * T, io->action, (size_t)T * sizeof(int32_t),
+                                      hipMemcpyDeviceToDevice, st));
+            }
+            MZ_TRY_(mz_infer_recurrent_step(net, pool, s + 1 < N, io->hidden, io->parent_block, (int64_t)T * H, io->action,
+                                            io->hidden + (size_t)(s + 1) * T * H,
+                                            trace ? io->trace_reward + (size_t)s * T : io->reward,
+                                            trace ? io->trace_value + (size_t)s * T : io->value,
+                                            trace ? io->trace_logits + (size_t)s * T * A : io->logits));
+            if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
         }
-        MZ_TRY_(mz_infer_recurrent_step(net, pool, s + 1 < N, io->hidden, io->parent_block, (int64_t)T * H, io->action,
-                                        io->hidden + (size_t)(s + 1) * T * H,
-                                        trace ? io->trace_reward + (size_t)s * T : io->reward,
-                                        trace ? io->trace_value + (size_t)s * T : io->value,
-                                        trace ? io->trace_logits + (size_t)s * T * A : io->logits));
-        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(ev[4 * s + 2]), static_cast<hipStream_t>(io->stream)));
     }
     if (ev) MZ_TRY_(mz_net_set_mid_event(net, nullptr));
     if (io->out_action)

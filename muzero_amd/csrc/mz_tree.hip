@@ -494,6 +494,24 @@ int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block) 
     return MZ_OK;
 }
 
+int mz_pool_begin_run(mz_pool* pool, int num_simulations, bool final_select, int* out_first_block) {
+    if (!pool->pending) return mz::fail(MZ_ERR_STATE, "expand_backprop without a preceding select");
+    const int nb = pool->blocks_in_use;
+    if (num_simulations < 1) return mz::fail(MZ_ERR_INVALID_ARG, "num_simulations must be >= 1 (got %d)", num_simulations);
+    if (nb + num_simulations - 1 + (final_select ? 1 : 0) > pool->dev.N)
+        return mz::fail(MZ_ERR_STATE, "%d more simulations%s on a pool with %d of %d done", num_simulations,
+                        final_select ? " and a select" : "", nb - 1, pool->dev.N);
+    *out_first_block = nb;
+    return MZ_OK;
+}
+
+void mz_pool_commit_run(mz_pool* pool, int num_simulations, bool final_select) {
+    pool->select_launches += num_simulations - (final_select ? 0 : 1);
+    pool->backprop_launches += num_simulations;
+    pool->blocks_in_use += num_simulations;
+    pool->pending = final_select;
+}
+
 void mz_pool_commit_backprop(mz_pool* pool, bool with_select) {
     if (with_select) pool->select_launches++;
     pool->backprop_launches++;
