@@ -342,6 +342,27 @@ class Network:
                                                 action.data_ptr(), hidden_pool[out_block].data_ptr(),
                                                 reward.data_ptr(), value.data_ptr(), logits.data_ptr(), None))
 
+    def run_simulations_pool(self, pool, num_simulations, hidden_pool, reward, value, logits, final_select=False,
+                             trace=None):
+        """run_mcts (reference agent.py:198-211) on a TreePool that holds a pending selection: `num_simulations` times
+        { recurrent inference of the selected leaves' parents, expand_node, backpropagate, select_leaf of the next
+        simulation } -- mz_infer_recurrent_run: ONE launch for the CartPole network, a simulation at a time otherwise.
+        The pool's parent/action tensors carry the selection in and (with `final_select`) the next one out; reward /
+        value / logits [T] / [T] / [T,A] receive the last simulation's outputs, or with `trace` = dict of
+        reward/value [n,T], logits [n,T,A], parent/action [n,T] tensors every simulation's."""
+        self._sync_stream()
+        pool._sync_stream()
+        n_blocks, T, H = hidden_pool.shape
+        if H != self.hidden_size or not hidden_pool.is_contiguous() or hidden_pool.dtype != torch.float32 or T != pool.T:
+            raise MuZeroError(f'hidden_pool must be a contiguous float32 [blocks, {pool.T}, {self.hidden_size}] tensor')
+        ptr = lambda t: None if t is None else t.data_ptr()
+        out = trace if trace is not None else dict(reward=reward, value=value, logits=logits)
+        _lib.check(self._lib.mz_infer_recurrent_run(
+            self._h, pool._h, int(num_simulations), int(bool(final_select)), hidden_pool.data_ptr(),
+            pool._parent.data_ptr(), T * H, pool._action.data_ptr(), ptr(out['reward']), ptr(out['value']),
+            ptr(out['logits']), T if trace is not None else 0, ptr(out.get('parent')), ptr(out.get('action'))))
+        return pool._parent, pool._action
+
     def initial_inference_pool(self, observation, hidden_pool, value, logits):
         """initial_inference writing the root hidden states into hidden_pool[0]."""
         self._sync_stream()

@@ -411,6 +411,71 @@ def test_native_move_with_unfused_tree_step(game):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize('game', ['cartpole', 'tictactoe'])
+def test_run_of_simulations_in_chunks(game):
+    """mz_infer_recurrent_run (reference agent.py:198-211; CartPole: all simulations of the call in one launch, the trees
+    in LDS meanwhile) called twice on one pool -- a first chunk that ends with a select, a second one that continues from
+    records the first left in the pool -- gives the move of one call, bit for bit: statistics, sampled actions, every
+    record of sampled trees, the traced selections and outputs."""
+    import torch
+    from muzero_amd.games import cartpole, tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[game]
+    T, N, first = 150, 12, 5
+    config = mod.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights(game, 11))
+    A = config.game_config.action_space_size
+    g = torch.Generator(device='cuda').manual_seed(5)
+    if game == 'tictactoe':
+        obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    else:
+        obs = (torch.rand(T, 4, generator=g, device='cuda') * 2 - 1) * torch.tensor([2.4, 3.0, 0.2, 3.0], device='cuda')
+    noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    n_legal = torch.full((T,), A, dtype=torch.int32, device='cuda')
+    n_legal[::13] = 0                                                     # some finished games
+    legal = torch.arange(A, dtype=torch.int32, device='cuda').repeat(T, 1).contiguous()
+    search = LockstepSearch(config, net, num_trees=T)
+    pool = search.pool
+    trace_a = {}
+    a = [x.clone() for x in search.run_native(obs, noise, u, temp, legal, n_legal, trace=trace_a)]
+    trees = [1, 2, 77, T - 1]
+    blocks_a = [[pool.read_block(t, e) for e in range(N + 1)] for t in trees]
+
+    pool.reset()
+    net.initial_inference_pool(obs, search.hidden, search.root_value_net, search.logits)
+    pool.expand_roots(search.logits, legal, n_legal, logits=True)
+    pool.add_root_noise(noise, search.frac)
+    pool.select()
+    mk = lambda n: dict(reward=torch.zeros(n, T, device='cuda'), value=torch.zeros(n, T, device='cuda'),
+                        logits=torch.zeros(n, T, A, device='cuda'),
+                        parent=torch.zeros(n, T, dtype=torch.int32, device='cuda'),
+                        action=torch.zeros(n, T, dtype=torch.int32, device='cuda'))
+    t1, t2 = mk(first), mk(N - first)
+    net.run_simulations_pool(pool, first, search.hidden, None, None, None, final_select=True, trace=t1)
+    assert pool.num_blocks == first + 1
+    net.run_simulations_pool(pool, N - first, search.hidden, None, None, None, final_select=False, trace=t2)
+    assert pool.num_blocks == N + 1
+    visits, root_value, minmax, policy = pool.root_stats()
+    chosen = pool.select_action(u, temp)
+    active = n_legal > 0
+    for x, y in zip(a, (visits, root_value, minmax, policy, chosen)):
+        assert torch.equal(x[active], y[active])
+    for k in ('reward', 'value', 'logits', 'parent', 'action'):
+        both = torch.cat([t1[k], t2[k]])
+        assert torch.equal(both[:, active], trace_a[k][:, active]), k
+    for t, ref in zip(trees, blocks_a):
+        for e in range(N + 1):
+            got = pool.read_block(t, e)
+            for k in ref[e]:
+                np.testing.assert_array_equal(ref[e][k], got[k], err_msg=f'tree {t} block {e} {k}')
+    from muzero_amd.exceptions import MuZeroError
+    with pytest.raises(MuZeroError):                                      # the pool is full
+        net.run_simulations_pool(pool, 1, search.hidden, search.reward, search.value, search.logits)
+
+
 @pytest.mark.parametrize('lanes', [2, 3])
 def test_pipelined_lanes_equal_one_lockstep_search(lanes):
     """PipelinedSearch (games split into lanes on separate HIP streams) returns what one LockstepSearch over the same
