@@ -1537,9 +1537,6 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
     // biases, 7 value bias, 8 / 9 policy weights
     __shared__ __attribute__((aligned(16))) float sBias[10 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n16 = lane & 15, g = lane >> 4;
-    const int lcol0 = wave * 32 + 4 * g;                 // this lane's four output columns of game n16 in the wave's first
-                                                         // 16-column block; the second block's are 16 further
     const int row0 = blockIdx.x * ROWS;
     const int nrec = nb0 + nsim;
     const CartRunLayout L = cart_run_layout(nrec, p.N);
@@ -1628,31 +1625,38 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
     MZ_TRACE_DECL;
     MZ_TRACE(0);                                         // prologue: weights, trees and tables in place
 
-    // the tree step's lanes: wave 0, lanes 0..31 = 16 games x 2; the others come along inactive, outside every tree
-    const int ltree = tid < ROWS * G ? tid / G : ROWS, gl = tid % G;
-    const bool tree_active = tid < ROWS * G && row0 + ltree < p.T && q.n_root[ltree] > 0;
     const LdsLog lds_log = (LdsLog)sLog;
     float vmax = 0.f;
-    auto bias4 = [&](int r, int c) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0 + 16 * c); };
-    auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
-        v[0] = fmaxf(acc[0] + bias.x, 0.f);
-        v[1] = fmaxf(acc[1] + bias.y, 0.f);
-        v[2] = fmaxf(acc[2] + bias.z, 0.f);
-        v[3] = fmaxf(acc[3] + bias.w, 0.f);
-    };
-    auto store4 = [&](const float (&v)[4], _Float16* sOutT, int c) {
-        uint2 h, l;
-        split4(v, h, l, vmax);
-        *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + lcol0 + 16 * c) = h;
-        *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + 128 + lcol0 + 16 * c) = l;
-    };
-    auto dot4 = [&](const float (&v)[4], const float4& wv) {
-        return __builtin_fmaf(v[3], wv.w, __builtin_fmaf(v[2], wv.z, __builtin_fmaf(v[1], wv.y, v[0] * wv.x)));
-    };
 
 #pragma unroll 1
     for (int i = 0; i < nsim; ++i) {
         asm volatile("" ::: "memory");                   // nothing below is hoisted out of the loop (registers)
+        // Every per-lane address and mask below derives from a copy of the thread index the compiler cannot see through:
+        // hoisted out of the loop they would have to live beside 384 registers of weights (they spilled).
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+        const int lcol0 = wave * 32 + 4 * g;             // this lane's four output columns of game n16 in the wave's first
+                                                         // 16-column block; the second block's are 16 further
+        // the tree step's lanes: wave 0, lanes 0..31 = 16 games x 2; the others come along inactive, outside every tree
+        const int ltree = tid < ROWS * G ? tid / G : ROWS, gl = tid % G;
+        const bool tree_active = tid < ROWS * G && row0 + ltree < p.T && q.n_root[min(ltree, ROWS - 1)] > 0;
+        auto bias4 = [&](int r, int c) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0 + 16 * c); };
+        auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
+            v[0] = fmaxf(acc[0] + bias.x, 0.f);
+            v[1] = fmaxf(acc[1] + bias.y, 0.f);
+            v[2] = fmaxf(acc[2] + bias.z, 0.f);
+            v[3] = fmaxf(acc[3] + bias.w, 0.f);
+        };
+        auto store4 = [&](const float (&v)[4], _Float16* sOutT, int c) {
+            uint2 h, l;
+            split4(v, h, l, vmax);
+            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + lcol0 + 16 * c) = h;
+            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + 128 + lcol0 + 16 * c) = l;
+        };
+        auto dot4 = [&](const float (&v)[4], const float4& wv) {
+            return __builtin_fmaf(v[3], wv.w, __builtin_fmaf(v[2], wv.z, __builtin_fmaf(v[1], wv.y, v[0] * wv.x)));
+        };
         const int nb = nb0 + i;
         const bool keep = out_stride != 0 || i + 1 == nsim;       // outputs no later simulation overwrites
         if (tid < ROWS) {
