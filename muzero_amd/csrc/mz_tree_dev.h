@@ -80,7 +80,9 @@ __device__ __forceinline__ BackSlot* f_back(const PoolDev& p, char* r) { return 
 // ---------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int x) {
-    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+    // every lane is written (full row / bank masks, permutations inside a row): the destination's old value is
+    // irrelevant, and left undefined the compiler neither copies x first nor keeps the move apart from its consumer
+    return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {
@@ -92,8 +94,18 @@ __device__ __forceinline__ double dpp_f64(double x) {
 }
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
-__device__ __forceinline__ double max_f64(double a, double b) { return __builtin_fmax(a, b); }   // operands are never NaN:
-__device__ __forceinline__ double min_f64(double a, double b) { return __builtin_fmin(a, b); }   // one v_max_f64 / v_min_f64
+// operands are never NaN: exactly one v_max_f64 / v_min_f64 each (through the builtins the compiler first canonicalises
+// every operand, an extra v_max_f64 x, x per operand and reduction step)
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ int max_i32(int a, int b) { return b > a ? b : a; }
 
 template <int G, bool MAX>
