@@ -665,6 +665,23 @@ __device__ __forceinline__ int sorted_slot(int A, int i, float pi, F&& pj) {
     return 1 + rank;
 }
 
+// The same rank over a row of priors staged in LDS (16-byte aligned, readable up to the next multiple of four past A):
+// four priors per LDS read, where the generic loop pays an LDS round trip per prior.
+__device__ __forceinline__ int sorted_slot_lds(int A, int i, float pi, const float* row) {
+    int rank = 0;
+#pragma unroll 2
+    for (int j0 = 0; j0 < A; j0 += 4) {
+        const float4 x4 = *reinterpret_cast<const float4*>(row + j0);
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            rank += (j >= 1 && j < A && (xs[u] > pi || (xs[u] == pi && j > i))) ? 1 : 0;
+        }
+    }
+    return 1 + rank;
+}
+
 // pol_row: this tree's A priors or logits (global or LDS); rnew, value_f32: its scalarised reward and value.
 // lds_row: this group's TreeLds<G>::kRow floats of LDS (16-byte aligned), or nullptr (then PB must be 1, and the
 // softmax of an action axis wider than the group goes through global memory and a workgroup barrier).
@@ -721,7 +738,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         for (int k = gl; k < A; k += G) {
             const float pr = lds_row[k];
             int slot = k;
-            if (sorted && k >= 1) slot = sorted_slot(A, k, pr, [&](int j) { return lds_row[j]; });
+            if (sorted && k >= 1) slot = sorted_slot_lds(A, k, pr, lds_row);
             if (active) {
                 Slot* s = slots + slot;
                 s->count = 0;
