@@ -1497,7 +1497,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 constexpr int kCartRunRS = 80, kCartRunOffBack = 48;
 struct CartRunLayout {          // byte offsets inside the dynamic LDS block
-    int recs, root_prior, root_vsum, mm_min, mm_max, sum_len, sims, path, log, ints, total;
+    int recs, root_prior, root_vsum, mm_min, mm_max, sum_len, sims, path, log, xtab, ints, total;
 };
 __host__ __device__ inline CartRunLayout cart_run_layout(int nrec, int N) {
     CartRunLayout L;
@@ -1511,10 +1511,105 @@ __host__ __device__ inline CartRunLayout cart_run_layout(int nrec, int N) {
     L.sims = o;        o += 16 * 8;
     L.path = o;        o += 16 * (N + 1) * 8;
     L.log = o;         o += (N + 2) * 8;
+    L.xtab = o;        o += (N + 2) * (N + 1) * 8;     // exploration_function(Np, Nc) for every pair of counts
     L.ints = o;        o += 5 * 16 * 4;          // n_root, root_count, path_len, parent, action
     L.total = (o + 15) & ~15;
     return L;
 }
+// select_leaf (agent.py:177-190) for a tree with TWO actions held in LDS, by the four lanes of a DPP quad: select_tree /
+// scan_level of mz_tree_dev.h with what two children leave of them.  A node's prefix is always both children (hi + 2 >= 2),
+// lanes 0 and 1 score one child each, every lane of the quad learns both scores through quad broadcasts and takes the
+// same decision: first child if either score is NaN (trap T2: a NaN first child wins, a NaN second child never does), else
+// the larger score, ties to the larger (action, slot) key (trap T1).  The exploration factor 2 log(Np + 1) / (Nc + 1)
+// (config.py:159-160) comes from `xtab`, filled in the kernel's prologue by the same IEEE division, so a level is an LDS
+// read of the slot, one of the table, a multiply-add and the exchange.  Same path entries, hi words and outputs as
+// select_tree, bit for bit (tests/test_selfplay_gpu.py, tests/test_fullsize_gpu.py).
+template <int LANE>
+__device__ __forceinline__ int quad_bcast(int x) {
+    return __builtin_amdgcn_mov_dpp(x, LANE * 0x55, 0xf, 0xf, true);      // quad_perm:[LANE, LANE, LANE, LANE]
+}
+template <int LANE>
+__device__ __forceinline__ double quad_bcast(double x) {
+    return __hiloint2double(quad_bcast<LANE>(__double2hiint(x)), quad_bcast<LANE>(__double2loint(x)));
+}
+__device__ __forceinline__ void cart2_select(const PoolDev& q, const double* xtab, int lt, bool active, int gl,
+                                             int* out_parent, int* out_action) {
+    const int N1 = q.N + 1;
+    int e = 0, np_ = 0, target = 0, depth = 0, hi = 0;
+    int* hi_home = nullptr;
+    int hi_word = 0;
+    bool done = !active;
+    bool ident = false;
+    double na = q.kmin, nd = q.kmax - q.kmin;
+    if (active) {
+        np_ = q.root_count[lt];
+        target = q.n_root[lt];
+        if (!q.has_bounds) {
+            const double mn = q.mm_min[lt], mx = q.mm_max[lt];
+            ident = (mx == mn);
+            na = mn;
+            nd = mx - mn;
+        }
+    }
+    const double dflt = ident ? q.default_value : (q.default_value - na) / nd;      // utils.py:68-76 on the default value
+    const bool renorm = !q.has_bounds && !ident;
+    for (int it = 0; it <= q.N; ++it) {          // a path holds at most N+1 nodes: the wave reaches the exit
+        if (!__any(!done)) break;
+        const bool root = (it == 0);
+        Slot* slots = f_slots(q, rec(q, lt, done ? 0 : e));
+        double sc = 0.0;
+        int c = 0, ch = 0, act = 0;
+        if (!done && gl < target) {
+            const Slot s = slots[gl];
+            c = s.count;
+            ch = s.child_hi;
+            act = s.act;
+            const double pr = root ? q.root_prior[lt * 2 + gl] : (double)s.prior;
+            double x = dflt;
+            if (c > 0) x = renorm ? (s.q - na) / nd : s.q;
+            sc = x + pr * xtab[np_ * N1 + c];                           // agent.py:189-190
+        }
+        const double sc0 = quad_bcast<0>(sc), sc1 = quad_bcast<1>(sc);
+        const int c0 = quad_bcast<0>(c), c1 = quad_bcast<1>(c);
+        const int ch0 = quad_bcast<0>(ch), ch1 = quad_bcast<1>(ch);
+        const int act0 = quad_bcast<0>(act), act1 = quad_bcast<1>(act);
+        int k = 0;
+        if (target >= 2 && sc0 == sc0 && sc1 == sc1)
+            k = (sc1 > sc0 || (sc1 == sc0 && ((act1 << 16) | 1) > (act0 << 16))) ? 1 : 0;
+        const int wc = k ? c1 : c0, wch = k ? ch1 : ch0, wact = k ? act1 : act0;
+        if (!done) {
+            if (gl == 0) q.path[lt * N1 + depth] = make_int2((e << kPathShift) | k, wc);
+            if (wc > 0) {                    // visited <=> expanded: descend (agent.py:179-180)
+                hi_home = &slots[k].child_hi;
+                hi_word = wch;
+                np_ = wc;
+                e = wch & kChildMask;
+                hi = (int)((unsigned)wch >> kChildBits);
+                target = min(hi + 2, 2);
+                ++depth;
+            } else {
+                done = true;
+                if (gl == 0) {
+                    out_parent[lt] = e;
+                    out_action[lt] = wact;
+                    q.path_len[lt] = depth + 1;
+                    if (!root && k + 1 > hi) *hi_home = (min(k + 1, kMaxActions - 1) << kChildBits) | (hi_word & kChildMask);
+                }
+            }
+        }
+    }
+    if (active && !done && gl == 0) {        // unreachable for a consistent pool; never leave outputs unset
+        out_parent[lt] = -1;
+        out_action[lt] = -1;
+        q.path_len[lt] = 0;
+        atomicOr(q.err_flag, 1);
+    }
+    if (!active && gl == 0) {
+        out_parent[lt] = -1;
+        out_action[lt] = -1;
+    }
+}
+
 constexpr int kCartRunMaxDynLds = 120 * 1024;    // beside ~36 KB of static LDS
 
 constexpr int kRunThreads = 256;      // four wavefronts, one per SIMD: 512 registers a lane, 384 of them weights
@@ -1524,7 +1619,7 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
                                                                     float* out_logits, long out_stride, int* trace_parent,
                                                                     int* trace_action) {
     constexpr int ROWS = 16;
-    constexpr int G = 2, PB = TreeLds<G>::kPB;
+    constexpr int G = 4, PB = TreeLds<G>::kPB;      // lanes per tree HERE (results do not depend on it): wave 0 = 16 trees x 4
     extern __shared__ __attribute__((aligned(16))) char sTree[];
     __shared__ __attribute__((aligned(16))) float sTreeRows[ROWS * TreeLds<G>::kRow];
     __shared__ float sOut[ROWS][4];                  // reward, value, the two logits: the tree step's inputs
@@ -1564,6 +1659,7 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
     int* sParent = sInts + 48;
     int* sAction = sInts + 64;
     double* sLog = reinterpret_cast<double*>(sTree + L.log);
+    double* sXtab = reinterpret_cast<double*>(sTree + L.xtab);
 
     // the weights, resident for the whole run: six stages x two 16-column blocks x 32 registers
     BFrag16 wc[2], wd[2], wr[2], w1[2], w2[2], wv[2];
@@ -1590,6 +1686,10 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
             q.path[idx] = row0 + t < p.T ? p.path[(size_t)(row0 + t) * (p.N + 1) + d] : make_int2(0, 0);
         }
         for (int idx = tid; idx < p.N + 2; idx += kRunThreads) sLog[idx] = p.log_table[idx];
+        for (int idx = tid; idx < (p.N + 2) * (p.N + 1); idx += kRunThreads) {      // config.py:159-160, as scan_level divides
+            const int np_ = idx / (p.N + 1), c = idx - np_ * (p.N + 1);
+            sXtab[idx] = p.log_table[np_] / (double)(c + 1);
+        }
         if (tid < ROWS) {
             const int t = row0 + tid;
             const bool in = t < p.T;
@@ -1625,7 +1725,6 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
     MZ_TRACE_DECL;
     MZ_TRACE(0);                                         // prologue: weights, trees and tables in place
 
-    const LdsLog lds_log = (LdsLog)sLog;
     float vmax = 0.f;
 
 #pragma unroll 1
@@ -1819,7 +1918,7 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
                 // a tree's two lanes lie inside this wavefront, whose LDS operations are performed in program order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                select_tree<G>(q, tid < ROWS * G ? ltree : q.T, tree_active, gl, sParent, sAction, lds_log);
+                cart2_select(q, sXtab, lt, tree_active, gl, sParent, sAction);
             }
         }
         __syncthreads();                                 // also: this simulation's hidden rows are visible to the gathers to come
