@@ -1610,6 +1610,87 @@ __device__ __forceinline__ void cart2_select(const PoolDev& q, const double* xta
     }
 }
 
+template <int LANE>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(quad_bcast<LANE>(__float_as_int(x)));
+}
+// expand_node + backpropagate (agent.py:154-160, 192-196) for the same trees and lanes: backprop_tree<G, true> of
+// mz_tree_dev.h for two actions.  The new record's two slots are (count 0, prior, action) in action order -- with two
+// actions the ranking by prior leaves slot 1 where it is and hi is 1 either way; masked_policy's fp32 sum of two terms is
+// (0 + e0) + e1.  The path is backed up four positions a round from the leaf down: each lane fetches the entry, slot
+// and reward of one position, the four rewards go round the quad by DPP, every lane replays the fp64 recurrence
+// value = reward + discount * value (agent.py:195, separately rounded) and keeps the value that reached its position,
+// then updates its slot (backup_slot: the same code).  Same records, root statistics, min/max and counters, bit for bit.
+__device__ __forceinline__ void cart2_backprop(const PoolDev& q, int lt, bool active, int gl, int nb, float logit0,
+                                               float logit1, float rnew, float value_f32) {
+    const int N1 = q.N + 1;
+    const int len = active ? q.path_len[lt] : 0;
+    {   // masked_policy over both actions (network.py:142-146): exp, NumPy-ordered fp32 sum, IEEE divide
+        const float e0 = expf(logit0), e1 = expf(logit1);
+        const float total = (0.f + e0) + e1;
+        const float pr = (gl == 0 ? e0 : e1) / total;
+        if (active && gl < 2) {
+            Slot* s = f_slots(q, rec(q, lt, nb)) + gl;
+            s->count = 0;
+            s->prior = pr;
+            s->act = gl;
+        }
+    }
+    double v = active ? (double)value_f32 : 0.0;
+    const int top = len - 1;
+    double mn_l = std::numeric_limits<double>::infinity();
+    double mx_l = -std::numeric_limits<double>::infinity();
+    for (int base = 0; base <= q.N; base += 4) {          // bounded: a path holds at most N+1 nodes
+        if (!__any(base < len)) break;
+        const int pos = top - base - gl;
+        const bool has = active && base < len && pos >= 0;
+        int c = 0, k = 0;
+        double vs = 0.0;
+        float rw = 0.f;
+        char* r = rec(q, lt, 0);
+        if (has) {
+            const int2 pe = q.path[lt * N1 + pos];
+            k = pe.x & (kMaxActions - 1);
+            r = rec(q, lt, pe.x >> kPathShift);
+            c = pe.y;
+            const BackSlot b = f_back(q, r)[k];
+            vs = b.vsum;
+            rw = (pos == top) ? rnew : b.reward;
+        }
+        const float r0 = quad_bcast<0>(rw), r1 = quad_bcast<1>(rw), r2 = quad_bcast<2>(rw), r3 = quad_bcast<3>(rw);
+        const int n_here = base < len ? min(4, len - base) : 0;
+        double vin = v;
+        // lane j of the round owns position top - base - j: it keeps the value that reaches it, then the value moves on
+        if (0 < n_here) v = (double)r0 + q.discount * v;
+        if (gl == 1) vin = v;
+        if (1 < n_here) v = (double)r1 + q.discount * v;
+        if (gl == 2) vin = v;
+        if (2 < n_here) v = (double)r2 + q.discount * v;
+        if (gl == 3) vin = v;
+        if (3 < n_here) v = (double)r3 + q.discount * v;
+        if (has) backup_slot(q, r, k, c, vs, vin, rw, pos == top, nb, 1, mn_l, mx_l);
+    }
+    if (active && gl == 0) {                          // the root (reward None -> chain ends, agent.py:195)
+        const int rc = q.root_count[lt] + 1;
+        const double rvs = q.root_vsum[lt] + v;
+        q.root_count[lt] = rc;
+        q.root_vsum[lt] = rvs;
+        const double mean = rvs / (double)rc;
+        if (mean > mx_l) mx_l = mean;
+        if (mean < mn_l) mn_l = mean;
+        q.sum_len[lt] += len;
+        q.sims[lt] += 1;
+    }
+    if (!q.has_bounds) {
+        mx_l = group_minmax_f64<4, true>(mx_l);
+        mn_l = group_minmax_f64<4, false>(mn_l);
+        if (active && gl == 0) {
+            if (mx_l > q.mm_max[lt]) q.mm_max[lt] = mx_l;
+            if (mn_l < q.mm_min[lt]) q.mm_min[lt] = mn_l;
+        }
+    }
+}
+
 constexpr int kCartRunMaxDynLds = 120 * 1024;    // beside ~36 KB of static LDS
 
 constexpr int kRunThreads = 256;      // four wavefronts, one per SIMD: 512 registers a lane, 384 of them weights
@@ -1619,13 +1700,12 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
                                                                     float* out_logits, long out_stride, int* trace_parent,
                                                                     int* trace_action) {
     constexpr int ROWS = 16;
-    constexpr int G = 4, PB = TreeLds<G>::kPB;      // lanes per tree HERE (results do not depend on it): wave 0 = 16 trees x 4
+    constexpr int G = 4;                             // lanes per tree HERE (results do not depend on it): wave 0 = 16 DPP quads
     extern __shared__ __attribute__((aligned(16))) char sTree[];
-    __shared__ __attribute__((aligned(16))) float sTreeRows[ROWS * TreeLds<G>::kRow];
     __shared__ float sOut[ROWS][4];                  // reward, value, the two logits: the tree step's inputs
     __shared__ __attribute__((aligned(16))) _Float16 sBuf[2][ROWS * kLdW];      // split activation tiles
     __shared__ __attribute__((aligned(16))) float sV[ROWS * kLd];                // the 101 value logits, f32
-    __shared__ float sPart[3][8][ROWS];              // reward / policy 0 / policy 1 partial dots of the eight waves
+    __shared__ float sPart[3][8][ROWS];              // reward / policy 0 / policy 1 partial dots of the eight column blocks
     __shared__ long sRowOff[ROWS];
     __shared__ float sAct[ROWS];
     // rows: 0 conv bias, 1 action plane, 2 hidden dense bias, 3 reward dense bias, 4 reward weights, 5 / 6 prediction dense
@@ -1909,13 +1989,10 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         MZ_TRACE(11);                                    // softmax, outputs
         if (wave == 0) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
             const int lt = tid < ROWS * G ? ltree : 0;
-            const BackupPrefetchT<PB> pf = backprop_prefetch<G, PB>(q, lt, tid < ROWS * G, gl);
             const float* mine = sOut[lt];
-            float* lds_row = sTreeRows + lt * TreeLds<G>::kRow;
-            backprop_tree<G, true, PB>(q, tid < ROWS * G ? ltree : q.T, tree_active, gl, nb, mine + 2, mine[0], mine[1], pf,
-                                       lds_row);
+            cart2_backprop(q, lt, tree_active, gl, nb, mine[2], mine[3], mine[0], mine[1]);
             if (i + 1 < nsim || final_select != 0) {
-                // a tree's two lanes lie inside this wavefront, whose LDS operations are performed in program order
+                // a tree's four lanes lie inside this wavefront, whose LDS operations are performed in program order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 cart2_select(q, sXtab, lt, tree_active, gl, sParent, sAction);
