@@ -1991,12 +1991,14 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
             const int lt = tid < ROWS * G ? ltree : 0;
             const float* mine = sOut[lt];
             cart2_backprop(q, lt, tree_active, gl, nb, mine[2], mine[3], mine[0], mine[1]);
+            MZ_TRACE(1);                                 // expand + backup
             if (i + 1 < nsim || final_select != 0) {
                 // a tree's four lanes lie inside this wavefront, whose LDS operations are performed in program order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 cart2_select(q, sXtab, lt, tree_active, gl, sParent, sAction);
             }
+            MZ_TRACE(9);                                 // select
         }
         __syncthreads();                                 // also: this simulation's hidden rows are visible to the gathers to come
     }

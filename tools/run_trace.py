@@ -8,9 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from muzero_amd import _lib
-NAMES = ['prologue', 'backup: prefetch', 'backup: expand', 'backup: chain+slots', 'backup: root+minmax',
+NAMES = ['prologue', 'expand + backup', 'backup: expand', 'backup: chain+slots', 'backup: root+minmax',
          'setup + gather', 'conv, dense, reward dense, pred 1', 'pred 2, value head', 'select: root stats',
-         'select: root level', 'select: other level', 'softmax + outputs']
+         'select', 'select: other level', 'softmax + outputs']
 wl = dict(bench.WORKLOADS['cartpole_1024x50']); wl['T'] = int(os.environ.get('TRACE_T', wl['T']))
 dev = torch.device('cuda', 0)
 move = bench.NetworkMove(wl, dev, 1234, 1)
