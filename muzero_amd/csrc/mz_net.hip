@@ -2132,14 +2132,21 @@ __device__ __forceinline__ void store_tile4(const f32x4 (&v)[4], _Float16* tile,
 
 constexpr int kAtariStageFloats = 16384;         // one split-f16 128 x 128 matrix = the bytes of 128 x 128 floats
 
-template <bool INITIAL>
-__global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, const float* __restrict__ in_base,
-                                                             const int* __restrict__ parent_block, long block_stride,
-                                                             const int* __restrict__ action, float* __restrict__ out_hidden,
-                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
-                                                             float* __restrict__ out_logits,
-                                                             float* __restrict__ out_value_raw) {
+// FUSE: 0 = the network alone; 1 = + expand and backprop of this simulation for the 64 games (mz_expand_backprop_logits),
+// 2 = + select of the next one (mz_step_logits): eight lanes per game, one pass of the 512 threads -- step_kernel's code
+// (mz_tree_dev.h; results do not depend on the lanes per tree), its LDS rows and log table laid over the activation
+// tiles, which are dead by then.  The backup's inputs are requested at the start and land while the network computes.
+// parent_block / action are then read at the start and rewritten at the end, each workgroup its own 64 games.
+constexpr int kAtariTreeG = 8, kAtariTreeP = 4;     // 18 children at the root: one round of 4 slots per lane
+template <bool INITIAL, int FUSE>
+__device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float* __restrict__ in_base, int* parent_block,
+                                           long block_stride, int* action, float* __restrict__ out_hidden,
+                                           float* __restrict__ out_reward, float* __restrict__ out_value,
+                                           float* __restrict__ out_logits, float* __restrict__ out_value_raw,
+                                           const PoolDev& p, int nb) {
     constexpr int ROWS = 64;
+    constexpr int TG = kAtariTreeG, TPB = TreeLds<TG>::kPB;
+    static_assert(ROWS * TG == kThreadsW, "one pass of the workgroup covers its 64 trees");
     __shared__ __attribute__((aligned(16))) _Float16 sT[4][ROWS * kLdW];      // X0, X1, Y0, Y1
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
     __shared__ float sOut[ROWS][20];                 // value, 18 logits, reward
@@ -2150,6 +2157,13 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
     const int lcol = wave * 16 + 4 * g;              // this lane's four columns: lcol .. lcol + 3
     const int row0 = blockIdx.x * ROWS;
     const float4* wlane = reinterpret_cast<const float4*>(INITIAL ? w.ini_s : w.rec_s) + wave * 64 + lane;
+    const int tree = FUSE ? row0 + tid / TG : 0, tgl = tid % TG;
+    bool tree_active = false;
+    BackupPrefetchT<TPB> pf;
+    if (FUSE) {
+        tree_active = tree < p.T && p.n_root[tree] > 0;
+        pf = backprop_prefetch<TG, TPB>(p, tree, tree < p.T, tgl);            // lands while the network computes
+    }
     BFragW bw;
     load_bw(bw, INITIAL ? w.ini_s : w.rec_s, lane, wave);
     float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
@@ -2370,6 +2384,43 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
     }
     note_range(vmax, w.range_flag);
     MZ_TRACE_NW(6);                                  // heads, outputs
+    if (FUSE) {
+        // tree step of these 64 games (agent.py:208-211, then 177-190 for the next simulation): the tiles are free
+        float* rows = reinterpret_cast<float*>(&sT[0][0]);
+        double* s_log = reinterpret_cast<double*>(rows + ROWS * TreeLds<TG>::kRow);
+        const LdsLog lds_log = stage_log_table(p, s_log);                     // contains a barrier: the heads' reads of tD are over
+        const float* mine = sOut[tid / TG];
+        backprop_tree<TG, true, TPB>(p, tree, tree_active, tgl, nb, mine + 1, mine[19], mine[0], pf,
+                                     rows + (tid / TG) * TreeLds<TG>::kRow);
+        if (FUSE == 2) {
+            // a tree's eight lanes lie inside one wavefront, whose vector memory operations are performed in program
+            // order: compiler ordering is enough (step_kernel, mz_tree.hip)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            select_tree<TG, kAtariTreeP>(p, tree, tree_active, tgl, parent_block, action, lds_log);
+        }
+    }
+}
+
+template <bool INITIAL>
+__global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, const float* __restrict__ in_base,
+                                                             const int* __restrict__ parent_block, long block_stride,
+                                                             const int* __restrict__ action, float* __restrict__ out_hidden,
+                                                             float* __restrict__ out_reward, float* __restrict__ out_value,
+                                                             float* __restrict__ out_logits,
+                                                             float* __restrict__ out_value_raw) {
+    atari_body<INITIAL, 0>(w, B, in_base, const_cast<int*>(parent_block), block_stride, const_cast<int*>(action), out_hidden,
+                           out_reward, out_value, out_logits, out_value_raw, PoolDev{}, 0);
+}
+
+template <bool SELECT>
+__global__ __launch_bounds__(kThreadsW, 1) void atari_step_kernel(AtariDev w, PoolDev p, int nb,
+                                                                  const float* __restrict__ in_base, int* parent_block,
+                                                                  long block_stride, int* action,
+                                                                  float* __restrict__ out_hidden, float* __restrict__ out_reward,
+                                                                  float* __restrict__ out_value, float* __restrict__ out_logits) {
+    atari_body<false, SELECT ? 2 : 1>(w, p.T, in_base, parent_block, block_stride, action, out_hidden, out_reward, out_value,
+                                      out_logits, nullptr, p, nb);
 }
 
 struct Packer {
@@ -3092,6 +3143,28 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
             cartpole16_step_kernel<false><<<grid, kThreads16, 0, net->stream>>>(net->cart, pool->dev, nb, hidden_base,
                                                                                parent_block, (long)block_stride, action,
                                                                                out_hidden, out_reward, out_value, out_logits);
+        if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
+        s = launch_status("recurrent inference + tree step");
+        if (s != MZ_OK) return s;
+        mz_pool_commit_backprop(pool, with_select != 0);
+        return MZ_OK;
+    }
+    // the Atari-shaped network: any lanes per tree in the pool (the fused kernel brings its own: results do not depend on it)
+    const bool fusable_atari = net->kind == MZ_NET_ATARI_SHAPED && pool->dev.A == 18 && pool->dev.N + 2 <= kLogLds;
+    if (fusable_atari) {                              // network and tree step of 64 games in one workgroup
+        int nb = 0;
+        int s = mz_pool_begin_backprop(pool, with_select != 0, &nb);
+        if (s != MZ_OK) return s;
+        MZ_HIP(hipSetDevice(net->device));
+        const int grid = (batch + 63) / 64;
+        if (with_select)
+            atari_step_kernel<true><<<grid, kThreadsW, 0, net->stream>>>(net->atari, pool->dev, nb, hidden_base, parent_block,
+                                                                        (long)block_stride, action, out_hidden, out_reward,
+                                                                        out_value, out_logits);
+        else
+            atari_step_kernel<false><<<grid, kThreadsW, 0, net->stream>>>(net->atari, pool->dev, nb, hidden_base, parent_block,
+                                                                         (long)block_stride, action, out_hidden, out_reward,
+                                                                         out_value, out_logits);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, net->stream));
         s = launch_status("recurrent inference + tree step");
         if (s != MZ_OK) return s;
