@@ -433,8 +433,9 @@ __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int
 template <int G>
 __device__ float numpy_sum_f32(const PoolDev& p, const float* a, float* scratch, int gl) {
     constexpr int W = G < 8 ? G : 8;
+    const bool one_leaf = p.n_sum_leaf == 1;      // n <= 128: the recursion is the leaf (0, A); nothing to read
     for (int s = 0; s < p.n_sum_leaf; ++s) {
-        const int lo = p.sum_leaf[2 * s], n = p.sum_leaf[2 * s + 1];
+        const int lo = one_leaf ? 0 : p.sum_leaf[2 * s], n = one_leaf ? p.A : p.sum_leaf[2 * s + 1];
         float res;
         if (n < 8) {
             res = 0.f;
@@ -502,13 +503,15 @@ struct TreeLds {
 // their lane 0.  Returns the sum in every lane of the group.
 template <int G>
 __device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int gl) {
+    // n <= 128: the recursion is the single leaf (0, A) -- known without the dependent global reads of the program
+    const bool one_leaf = p.n_sum_leaf == 1;
     if (G >= 8) {
         constexpr int OCT = G >= 8 ? G / 8 : 1;
         const int oct = gl >> 3, i = gl & 7;
         for (int s0 = 0; s0 < p.n_sum_leaf; s0 += OCT) {
             const int s = s0 + oct;
             const bool has = s < p.n_sum_leaf;
-            const int lo = has ? p.sum_leaf[2 * s] : 0, n = has ? p.sum_leaf[2 * s + 1] : 0;
+            const int lo = has && !one_leaf ? p.sum_leaf[2 * s] : 0, n = !has ? 0 : one_leaf ? p.A : p.sum_leaf[2 * s + 1];
             const int nfull = n - (n % 8);
             float r = 0.f;
             if (nfull >= 8) {
@@ -526,7 +529,7 @@ __device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a,
         }
     } else if (gl == 0) {
         for (int s = 0; s < p.n_sum_leaf; ++s) {
-            const int lo = p.sum_leaf[2 * s], n = p.sum_leaf[2 * s + 1];
+            const int lo = one_leaf ? 0 : p.sum_leaf[2 * s], n = one_leaf ? p.A : p.sum_leaf[2 * s + 1];
             const int nfull = n - (n % 8);
             float res = 0.f;
             if (nfull >= 8) {
@@ -584,6 +587,7 @@ template <int PB>
 struct BackupPrefetchT {
     int len, root_count;
     double root_vsum;
+    double mm_min, mm_max;       // the tree's MinMaxStats before this backup (pools without known bounds)
     int slot[PB], c[PB];
     double vs[PB];
     float rw[PB];
@@ -598,6 +602,7 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
     f.len = 0;
     f.root_count = 0;
     f.root_vsum = 0.0;
+    f.mm_min = f.mm_max = 0.0;
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         f.slot[j] = 0;
@@ -612,6 +617,10 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
         for (int j = 0; j < PB; ++j) pe[j] = p.path[(size_t)tree * (p.N + 1) + min(gl + G * j, p.N)];
         f.root_count = p.root_count[tree];
         f.root_vsum = p.root_vsum[tree];
+        if (!p.has_bounds) {
+            f.mm_min = p.mm_min[tree];
+            f.mm_max = p.mm_max[tree];
+        }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
             f.slot[j] = pe[j].x;
@@ -867,9 +876,9 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         // NaN means never enter mx_l / mn_l (the comparisons above are false), so these are plain reductions
         mx_l = group_minmax_f64<G, true>(mx_l);
         mn_l = group_minmax_f64<G, false>(mn_l);
-        if (active && gl == 0) {
-            if (mx_l > p.mm_max[tree]) p.mm_max[tree] = mx_l;
-            if (mn_l < p.mm_min[tree]) p.mm_min[tree] = mn_l;
+        if (active && gl == 0) {                      // nothing but this backup writes them: the prefetched values are current
+            if (mx_l > pf.mm_max) p.mm_max[tree] = mx_l;
+            if (mn_l < pf.mm_min) p.mm_min[tree] = mn_l;
         }
     }
     MZ_TRACE(4);                                 // backup: root and min/max updated

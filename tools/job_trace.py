@@ -11,7 +11,7 @@ TREE = os.environ.get('TRACE_TREE')      # build with -DMZ_TREE_TRACE only: stam
 NAMES = ['head', 'backup: prefetch', 'backup: expand', 'backup: chain+slots', 'backup: root+minmax', '', '', '',
          'select: root stats', 'select: root level', 'select: other level'] if TREE else ['prologue', 'stage set-up', 'MFMA section', 'commit / stores', 'barrier', 'after barrier', 'epilogue math']
 NAMES = [n for n in NAMES]
-wl = dict(bench.WORKLOADS['tictactoe_4096x25']); wl['T'] = int(os.environ.get('TRACE_T', wl['T']))
+wl = dict(bench.WORKLOADS[os.environ.get('TRACE_WL', 'tictactoe_4096x25')]); wl['T'] = int(os.environ.get('TRACE_T', wl['T']))
 dev = torch.device('cuda', 0)
 move = bench.NetworkMove(wl, dev, 1234, 1)
 lib = _lib.load()
@@ -21,7 +21,7 @@ read = lambda: lib.mz_debug_net_trace(ctypes.c_void_p(out.ctypes.data), ctypes.c
 move.run(); torch.cuda.synchronize(); read()
 move.run(); torch.cuda.synchronize(); read()
 launches = wl['N']
-used = out[:, PH] > 0
+used = out[:, PH:].sum(1) > 0
 clk, cnt = out[used, :PH].astype(np.float64) / launches, out[used, PH:].astype(np.float64) / launches
 print(int(used.sum()), 'wavefronts; shader clocks per wavefront and launch')
 for i, nm in enumerate(NAMES):
