@@ -411,6 +411,93 @@ def test_native_move_with_unfused_tree_step(game):
         assert torch.equal(x, y)
 
 
+def test_atari_fused_step_equals_separate_launches():
+    """The Atari-shaped native move (network and tree step of 64 games in one launch, eight lanes per tree) against the
+    Python-driven move (mz_infer_recurrent, then mz_step_logits with the pool's own lanes per tree): bit for bit, some
+    games finished, some roots with few legal actions."""
+    import torch
+    from muzero_amd.games import atari_shaped
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    T, N = 150, 14
+    config = atari_shaped.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights('atari', 6))
+    A = config.game_config.action_space_size
+    g = torch.Generator(device='cuda').manual_seed(4)
+    obs = torch.randn(T, 256, generator=g, device='cuda')
+    noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    n_legal = torch.full((T,), A, dtype=torch.int32, device='cuda')
+    n_legal[::9] = 0
+    n_legal[4::13] = 3
+    legal = torch.arange(A, dtype=torch.int32, device='cuda').repeat(T, 1).contiguous()
+    search = LockstepSearch(config, net, num_trees=T)
+
+    class NoHooks:
+        before_inference = after_inference = after_tree = staticmethod(lambda s: None)
+
+    a = [x.clone() for x in search.run(obs, noise, u, temp, legal, n_legal, hooks=NoHooks())]     # separate launches
+    blocks_a = [[search.pool.read_block(t, e) for e in range(N + 1)] for t in (1, 4, T - 1)]
+    b = [x.clone() for x in search.run(obs, noise, u, temp, legal, n_legal)]                       # native, fused
+    active = n_legal > 0
+    for x, y in zip(a, b):
+        assert torch.equal(x[active], y[active])
+    for t, ref in zip((1, 4, T - 1), blocks_a):
+        for e in range(N + 1):
+            got = search.pool.read_block(t, e)
+            for k in ref[e]:
+                np.testing.assert_array_equal(ref[e][k], got[k], err_msg=f'tree {t} block {e} {k}')
+
+
+@pytest.mark.parametrize('bounded', [True, False])
+def test_cartpole_run_kernel_equals_the_launch_per_simulation(bounded):
+    """The CartPole move whose simulations are one launch (trees in LDS, the two-action quad select / backup of
+    cartpole16_run_kernel) against the same move as one launch per simulation (a pool with four lanes per tree takes
+    mz_tree_dev.h's general tree code): bit for bit, with and without known value bounds (MinMaxStats live: first-
+    simulation NaN scores, renormalised exploitation terms, min/max updates), with roots of one legal action, roots
+    whose legal list is [1, 0], and finished games."""
+    import copy
+    import torch
+    from muzero_amd.games import cartpole
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    T, N = 203, 24
+    config = cartpole.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights('cartpole', 21))
+    if not bounded:
+        config = copy.copy(config)
+        config.value_config = copy.copy(config.value_config)
+        config.value_config.known_bounds = None
+    g = torch.Generator(device='cuda').manual_seed(8)
+    obs = (torch.rand(T, 4, generator=g, device='cuda') * 2 - 1) * torch.tensor([2.4, 3.0, 0.2, 3.0], device='cuda')
+    noise = torch.distributions.Dirichlet(torch.ones(2, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temp = torch.ones(T, dtype=torch.float64, device='cuda')
+    n_legal = torch.full((T,), 2, dtype=torch.int32, device='cuda')
+    legal = torch.arange(2, dtype=torch.int32, device='cuda').repeat(T, 1).contiguous()
+    n_legal[::11] = 0                                   # finished games
+    n_legal[5::17] = 1                                  # one legal action ...
+    legal[5::34, 0] = 1                                 # ... which is action 1 for half of them
+    legal[3::19] = torch.tensor([1, 0], dtype=torch.int32, device='cuda')       # both, listed in reverse
+    fast = LockstepSearch(config, net, num_trees=T)
+    slow = LockstepSearch(config, net, num_trees=T, lanes_per_tree=4)
+    ta, tb = {}, {}
+    a = [x.clone() for x in fast.run_native(obs, noise, u, temp, legal, n_legal, trace=ta)]
+    b = [x.clone() for x in slow.run_native(obs, noise, u, temp, legal, n_legal, trace=tb)]
+    active = n_legal > 0
+    for x, y in zip(a, b):
+        assert torch.equal(x[active], y[active])
+    for k in ('reward', 'value', 'logits', 'parent', 'action'):
+        assert torch.equal(ta[k][:, active], tb[k][:, active]), k
+    for t in (1, 3, 5, 39, T - 1):
+        for e in range(N + 1):
+            x, y = fast.pool.read_block(t, e), slow.pool.read_block(t, e)
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=f'tree {t} block {e} {k}')
+    assert fast.pool.counters()[:2].tolist() == slow.pool.counters()[:2].tolist()
+
+
 @pytest.mark.parametrize('game', ['cartpole', 'tictactoe'])
 def test_run_of_simulations_in_chunks(game):
     """mz_infer_recurrent_run (reference agent.py:198-211; CartPole: all simulations of the call in one launch, the trees
