@@ -1573,9 +1573,9 @@ __device__ __forceinline__ void cart2_select(const PoolDev& q, const double* xta
         const int c0 = quad_bcast<0>(c), c1 = quad_bcast<1>(c);
         const int ch0 = quad_bcast<0>(ch), ch1 = quad_bcast<1>(ch);
         const int act0 = quad_bcast<0>(act), act1 = quad_bcast<1>(act);
-        int k = 0;
-        if (target >= 2 && sc0 == sc0 && sc1 == sc1)
-            k = (sc1 > sc0 || (sc1 == sc0 && ((act1 << 16) | 1) > (act0 << 16))) ? 1 : 0;
+        // (action << 16 | slot) keys: slot 1's is larger iff act1 >= act0
+        const bool both = (target >= 2) & (sc0 == sc0) & (sc1 == sc1);
+        const int k = (both & ((sc1 > sc0) | ((sc1 == sc0) & (act1 >= act0)))) ? 1 : 0;
         const int wc = k ? c1 : c0, wch = k ? ch1 : ch0, wact = k ? act1 : act0;
         if (!done) {
             if (gl == 0) q.path[lt * N1 + depth] = make_int2((e << kPathShift) | k, wc);
@@ -1817,9 +1817,11 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
         const int lcol0 = wave * 32 + 4 * g;             // this lane's four output columns of game n16 in the wave's first
                                                          // 16-column block; the second block's are 16 further
-        // the tree step's lanes: wave 0, lanes 0..31 = 16 games x 2; the others come along inactive, outside every tree
-        const int ltree = tid < ROWS * G ? tid / G : ROWS, gl = tid % G;
-        const bool tree_active = tid < ROWS * G && row0 + ltree < p.T && q.n_root[min(ltree, ROWS - 1)] > 0;
+        // the tree step's lanes: wavefront 0 = 16 DPP quads = the 16 trees (spread over the four wavefronts, four trees
+        // each, the step was slower: 104 against 110 M simulations/s)
+        const bool tree_lane = wave == 0;
+        const int ltree = (lane >> 2) & 15, gl = lane & (G - 1);
+        const bool tree_active = tree_lane && row0 + ltree < p.T && q.n_root[ltree] > 0;
         auto bias4 = [&](int r, int c) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0 + 16 * c); };
         auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
             v[0] = fmaxf(acc[0] + bias.x, 0.f);
@@ -1987,8 +1989,8 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         }
         lds_barrier();
         MZ_TRACE(11);                                    // softmax, outputs
-        if (wave == 0) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
-            const int lt = tid < ROWS * G ? ltree : 0;
+        if (tree_lane) {      // tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
+            const int lt = ltree;
             const float* mine = sOut[lt];
             cart2_backprop(q, lt, tree_active, gl, nb, mine[2], mine[3], mine[0], mine[1]);
             MZ_TRACE(1);                                 // expand + backup
