@@ -1675,9 +1675,11 @@ __device__ __forceinline__ void cart2_backprop(const PoolDev& q, int lt, bool ac
         const double rvs = q.root_vsum[lt] + v;
         q.root_count[lt] = rc;
         q.root_vsum[lt] = rvs;
-        const double mean = rvs / (double)rc;
-        if (mean > mx_l) mx_l = mean;
-        if (mean < mn_l) mn_l = mean;
+        if (!q.has_bounds) {                          // MinMaxStats.update is a no-op under known bounds (utils.py:63-66)
+            const double mean = rvs / (double)rc;
+            if (mean > mx_l) mx_l = mean;
+            if (mean < mn_l) mn_l = mean;
+        }
         q.sum_len[lt] += len;
         q.sims[lt] += 1;
     }

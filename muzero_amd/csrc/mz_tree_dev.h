@@ -588,6 +588,7 @@ struct BackupPrefetchT {
     int len, root_count;
     double root_vsum;
     double mm_min, mm_max;       // the tree's MinMaxStats before this backup (pools without known bounds)
+    long long sum_len, sims;     // the tree's measurement counters (lane 0 of the group adds to them)
     int slot[PB], c[PB];
     double vs[PB];
     float rw[PB];
@@ -603,6 +604,7 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
     f.root_count = 0;
     f.root_vsum = 0.0;
     f.mm_min = f.mm_max = 0.0;
+    f.sum_len = f.sims = 0;
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         f.slot[j] = 0;
@@ -620,6 +622,10 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
         if (!p.has_bounds) {
             f.mm_min = p.mm_min[tree];
             f.mm_max = p.mm_max[tree];
+        }
+        if (gl == 0) {
+            f.sum_len = p.sum_len[tree];
+            f.sims = p.sims[tree];
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
@@ -866,11 +872,13 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         const double rvs = pf.root_vsum + v;
         p.root_count[tree] = rc;
         p.root_vsum[tree] = rvs;
-        const double mean = rvs / (double)rc;
-        if (mean > mx_l) mx_l = mean;
-        if (mean < mn_l) mn_l = mean;
-        p.sum_len[tree] += len;
-        p.sims[tree] += 1;
+        if (!p.has_bounds) {                          // MinMaxStats.update is a no-op under known bounds (utils.py:63-66)
+            const double mean = rvs / (double)rc;
+            if (mean > mx_l) mx_l = mean;
+            if (mean < mn_l) mn_l = mean;
+        }
+        p.sum_len[tree] = pf.sum_len + len;           // came with the prefetch: no dependent load at the end of the backup
+        p.sims[tree] = pf.sims + 1;
     }
     if (!p.has_bounds) {
         // NaN means never enter mx_l / mn_l (the comparisons above are false), so these are plain reductions
