@@ -91,6 +91,59 @@ __device__ __forceinline__ BackupInputs<G, PB> backup_inputs(const PoolDev& p, i
     return b;
 }
 
+// The network outputs' policy row of every tree of the workgroup and the log table, requested FIRST, before the backup's
+// inputs: they land in the round trip that brings the path entries, instead of costing one of their own later (the log
+// table before the barrier, the logits at the start of the expansion).  stage_requests() issues the loads;
+// stage_commit() parks them in LDS and ends with the workgroup barrier.  Rows wider than the LDS row stay in global memory.
+template <int G>
+struct EarlyStage {
+    static constexpr int KL = TreeLds<G>::kMaxA / G;      // policy entries per lane
+    float pv[KL];
+    double lt[kLogLds / kBlockThreads];
+};
+template <int G>
+__device__ __forceinline__ EarlyStage<G> stage_requests(const PoolDev& p, int tree, int gl, const float* pol) {
+    EarlyStage<G> e;
+    const bool row_ok = tree < p.T && p.A <= TreeLds<G>::kMaxA;
+#pragma unroll
+    for (int j = 0; j < EarlyStage<G>::KL; ++j) {
+        const int k = gl + j * G;
+        e.pv[j] = (row_ok && k < p.A) ? pol[(size_t)tree * p.A + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kLogLds / kBlockThreads; ++j) {
+        const int i = (int)threadIdx.x + j * kBlockThreads;
+        e.lt[j] = (p.N + 2 <= kLogLds && i < p.N + 2) ? p.log_table[i] : 0.0;
+    }
+    return e;
+}
+// returns the LDS log table (or nullptr); *pol_row is redirected to the staged row when it was staged
+template <int G>
+__device__ __forceinline__ LdsLog stage_commit(const PoolDev& p, const EarlyStage<G>& e, int gl, float* s_pol_row,
+                                               double* s_log, const float** pol_row) {
+    if (p.A <= TreeLds<G>::kMaxA) {
+#pragma unroll
+        for (int j = 0; j < EarlyStage<G>::KL; ++j) {
+            const int k = gl + j * G;
+            if (k < p.A) s_pol_row[k] = e.pv[j];
+        }
+        *pol_row = s_pol_row;
+    }
+    const bool log_ok = p.N + 2 <= kLogLds;
+    if (log_ok) {
+#pragma unroll
+        for (int j = 0; j < kLogLds / kBlockThreads; ++j) {
+            const int i = (int)threadIdx.x + j * kBlockThreads;
+            if (i < p.N + 2) s_log[i] = e.lt[j];
+        }
+    }
+    __syncthreads();
+    return log_ok ? (LdsLog)s_log : nullptr;
+}
+#define MZ_POL_LDS(G)                                                                                          \
+    __shared__ float s_pol[TreeLds<G>::kGroups * TreeLds<G>::kMaxA];                                            \
+    float* s_pol_row = s_pol + (threadIdx.x / G) * TreeLds<G>::kMaxA
+
 template <int G, bool LOGITS>
 __global__ __launch_bounds__(kBlockThreads) void backprop_kernel(PoolDev p, int nb, const float* pol,
                                                                  const float* reward, const float* value) {
@@ -113,10 +166,13 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     MZ_TREE_LDS(G);
+    MZ_POL_LDS(G);
     constexpr int PB = TreeLds<G>::kPB;
+    const EarlyStage<G> early = stage_requests<G>(p, tree, gl, pol);
     const BackupInputs<G, PB> b = backup_inputs<G, PB>(p, tree, gl, pol, reward, value);
-    const LdsLog lds_log = stage_log_table(p, s_log);
-    backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb, b.pol_row, b.reward, b.value, b.pf, lds_row);
+    const float* pol_row = b.pol_row;
+    const LdsLog lds_log = stage_commit<G>(p, early, gl, s_pol_row, s_log, &pol_row);
+    backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb, pol_row, b.reward, b.value, b.pf, lds_row);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
