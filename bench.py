@@ -254,9 +254,10 @@ class NetworkMove:
             self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
         elif wl['net'] == 'atari':       # synthetic (2,128) observations
             self.obs = torch.randn(T, 256, generator=g, device=device).contiguous()
-            # the whole network AND the tree step of a workgroup's 64 games are one launch (atari_step_kernel):
-            # input conv 4 taps x 146 x 128, 16 + 2 + 1 128x128 stages, reward 256, heads 128 x 19
-            self.dominant = 'atari_step_kernel'
+            # the N simulations of a move (whole network + tree step of a workgroup's 64 games, looped in the kernel) are ONE
+            # launch, atari_run_kernel (mz_infer_recurrent_run): per evaluation input conv 4 taps x 146 x 128,
+            # 16 + 2 + 1 128x128 stages, reward 256, heads 128 x 19
+            self.dominant = 'atari_run_kernel'
             self.flops_per_eval = 2 * (4 * 146 * 128 + 16 * 128 * 128 + 256 + 2 * 128 * 128 + 128 * 128 + 128 * 19)
         else:
             span = torch.tensor([2.4, 3.0, 0.21, 3.0], device=device)
@@ -270,7 +271,7 @@ class NetworkMove:
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
         self.hooks = MoveEvents(wl['N'], event_stride)
         self.evals_per_launch = self.trees_per_launch
-        if self.dominant == 'cartpole16_run_kernel':
+        if self.dominant in ('cartpole16_run_kernel', 'atari_run_kernel'):
             # mz_search_move records the first sampled simulation's events around the whole run: one launch = N evaluations
             # of every game
             self.hooks.sampled = self.hooks.sampled[:1]
@@ -473,14 +474,14 @@ def main():
                     'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
                     'executed_mfma_tflops': executed, 'executed_frac': executed / peak}
         rest_name = ('head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else
-                     'after_fused_kernel_us' if move.dominant in ('cartpole16_run_kernel', 'atari_step_kernel') else
+                     'after_fused_kernel_us' if move.dominant in ('cartpole16_run_kernel', 'atari_run_kernel') else
                      'tree_step_kernel_us')
-        if move.dominant == 'cartpole16_run_kernel':
+        if move.dominant in ('cartpole16_run_kernel', 'atari_run_kernel'):
             roofline['simulations_per_launch'] = wl['N']
             roofline['us_per_simulation'] = k1 * 1e6 / wl['N']
-            roofline['launch_includes'] = 'the tree steps of all its simulations (trees in LDS)'
-        elif move.dominant == 'atari_step_kernel':
-            roofline['launch_includes'] = 'the tree step (expand, backup, next select) of the 64 games of each workgroup'
+            roofline['launch_includes'] = ('the tree steps of all its simulations (trees in LDS)'
+                                           if move.dominant == 'cartpole16_run_kernel' else
+                                           'the tree steps (expand, backup, next select) of all its simulations')
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         if rest_name == 'tree_step_kernel_us':       # the tree step is a launch of its own: its HBM roofline beside it

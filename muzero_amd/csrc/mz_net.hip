@@ -2147,7 +2147,7 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
                                            long block_stride, int* action, float* __restrict__ out_hidden,
                                            float* __restrict__ out_reward, float* __restrict__ out_value,
                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw,
-                                           const PoolDev& p, int nb) {
+                                           const PoolDev& p, int nb, bool do_select = true) {
     constexpr int ROWS = 64;
     constexpr int TG = kAtariTreeG, TPB = TreeLds<TG>::kPB;
     static_assert(ROWS * TG == kThreadsW, "one pass of the workgroup covers its 64 trees");
@@ -2156,7 +2156,9 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
     __shared__ float sOut[ROWS][20];                 // value, 18 logits, reward
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                    // opaque: inside atari_run_kernel's loop nothing derived from it is hoisted
+    const int lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g = lane >> 4;
     const int lcol = wave * 16 + 4 * g;              // this lane's four columns: lcol .. lcol + 3
     const int row0 = blockIdx.x * ROWS;
@@ -2396,7 +2398,7 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
         const float* mine = sOut[tid / TG];
         backprop_tree<TG, true, TPB>(p, tree, tree_active, tgl, nb, mine + 1, mine[19], mine[0], pf,
                                      rows + (tid / TG) * TreeLds<TG>::kRow);
-        if (FUSE == 2) {
+        if (FUSE == 2 && do_select) {
             // a tree's eight lanes lie inside one wavefront, whose vector memory operations are performed in program
             // order: compiler ordering is enough (step_kernel, mz_tree.hip)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2415,6 +2417,35 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
                                                              float* __restrict__ out_value_raw) {
     atari_body<INITIAL, 0>(w, B, in_base, const_cast<int*>(parent_block), block_stride, const_cast<int*>(action), out_hidden,
                            out_reward, out_value, out_logits, out_value_raw, PoolDev{}, 0);
+}
+
+// run_mcts (agent.py:198-211) of 64 games in ONE launch: the body above, looped.  A workgroup's games, trees and hidden
+// rows are its own from the first simulation to the last (the rows a simulation gathers were written by this workgroup:
+// the barrier at the end of a simulation publishes them), so no launch boundary and no other workgroup's deepest tree
+// separates two simulations.  Outputs and traces as in cartpole16_run_kernel.
+__global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, PoolDev p, int nb0, int nsim, int final_select,
+                                                                 float* hidden_base, int* parent_block, long block_stride,
+                                                                 int* action, float* out_reward, float* out_value,
+                                                                 float* out_logits, long out_stride, int* trace_parent,
+                                                                 int* trace_action) {
+#pragma unroll 1
+    for (int i = 0; i < nsim; ++i) {
+        asm volatile("" ::: "memory");
+        if (trace_parent != nullptr && threadIdx.x < 64) {
+            const int b = blockIdx.x * 64 + threadIdx.x;
+            if (b < p.T) {
+                trace_parent[(size_t)i * p.T + b] = parent_block[b];
+                trace_action[(size_t)i * p.T + b] = action[b];
+            }
+        }
+        float* oh = hidden_base + (size_t)(nb0 + i) * block_stride;
+        float* orw = out_reward + (size_t)i * out_stride;
+        float* ov = out_value + (size_t)i * out_stride;
+        float* ol = out_logits + (size_t)i * out_stride * 18;
+        atari_body<false, 2>(w, p.T, hidden_base, parent_block, block_stride, action, oh, orw, ov, ol, nullptr, p, nb0 + i,
+                             i + 1 < nsim || final_select != 0);
+        __syncthreads();
+    }
 }
 
 template <bool SELECT>
@@ -3070,8 +3101,11 @@ static bool run_fusable_cart(const mz_net* net, const mz_pool* pool) {
     return net->kind == MZ_NET_CARTPOLE && pool->G == 2 && pool->dev.A == 2 && pool->dev.T <= kCart16MaxBatch &&
            pool->dev.off_back % 16 == 0 && cart_run_layout(pool->dev.N + 1, pool->dev.N).total <= kCartRunMaxDynLds;
 }
+static bool run_fusable_atari(const mz_net* net, const mz_pool* pool) {
+    return net->kind == MZ_NET_ATARI_SHAPED && pool->dev.A == 18 && pool->dev.N + 2 <= kLogLds;
+}
 __attribute__((visibility("hidden"))) int mz_net_run_is_one_launch(const mz_net* net, const mz_pool* pool) {
-    return run_fusable_cart(net, pool) ? 1 : 0;
+    return run_fusable_cart(net, pool) || run_fusable_atari(net, pool) ? 1 : 0;
 }
 
 int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
@@ -3098,6 +3132,19 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCartRunMaxDynLds));
         cartpole16_run_kernel<<<(T + 15) / 16, kRunThreads, dyn_lds, net->stream>>>(
             net->cart, pool->dev, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
+            out_reward, out_value, out_logits, (long)out_stride, trace_parent, trace_action);
+        s = launch_status("recurrent inference + tree step, all simulations");
+        if (s != MZ_OK) return s;
+        mz_pool_commit_run(pool, num_simulations, final_select != 0);
+        return MZ_OK;
+    }
+    if (run_fusable_atari(net, pool)) {
+        int nb0 = 0;
+        int s = mz_pool_begin_run(pool, num_simulations, final_select != 0, &nb0);
+        if (s != MZ_OK) return s;
+        MZ_HIP(hipSetDevice(net->device));
+        atari_run_kernel<<<(T + 63) / 64, kThreadsW, 0, net->stream>>>(
+            net->atari, pool->dev, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
             out_reward, out_value, out_logits, (long)out_stride, trace_parent, trace_action);
         s = launch_status("recurrent inference + tree step, all simulations");
         if (s != MZ_OK) return s;

@@ -498,17 +498,17 @@ def test_cartpole_run_kernel_equals_the_launch_per_simulation(bounded):
     assert fast.pool.counters()[:2].tolist() == slow.pool.counters()[:2].tolist()
 
 
-@pytest.mark.parametrize('game', ['cartpole', 'tictactoe'])
+@pytest.mark.parametrize('game', ['cartpole', 'tictactoe', 'atari'])
 def test_run_of_simulations_in_chunks(game):
-    """mz_infer_recurrent_run (reference agent.py:198-211; CartPole: all simulations of the call in one launch, the trees
-    in LDS meanwhile) called twice on one pool -- a first chunk that ends with a select, a second one that continues from
+    """mz_infer_recurrent_run (reference agent.py:198-211; CartPole and Atari-shaped: all simulations of the call in one
+    launch, CartPole's trees in LDS meanwhile) called twice on one pool -- a first chunk that ends with a select, a second one that continues from
     records the first left in the pool -- gives the move of one call, bit for bit: statistics, sampled actions, every
     record of sampled trees, the traced selections and outputs."""
     import torch
-    from muzero_amd.games import cartpole, tictactoe
+    from muzero_amd.games import atari_shaped, cartpole, tictactoe
     from muzero_amd.selfplay import LockstepSearch
     from oracle import net_oracle
-    mod = {'tictactoe': tictactoe, 'cartpole': cartpole}[game]
+    mod = {'tictactoe': tictactoe, 'cartpole': cartpole, 'atari': atari_shaped}[game]
     T, N, first = 150, 12, 5
     config = mod.make_config(num_simulations=N)
     net = config.network_config.network_class(config, weights=net_oracle.random_weights(game, 11))
@@ -516,6 +516,8 @@ def test_run_of_simulations_in_chunks(game):
     g = torch.Generator(device='cuda').manual_seed(5)
     if game == 'tictactoe':
         obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    elif game == 'atari':
+        obs = torch.randn(T, 256, generator=g, device='cuda')
     else:
         obs = (torch.rand(T, 4, generator=g, device='cuda') * 2 - 1) * torch.tensor([2.4, 3.0, 0.2, 3.0], device='cuda')
     noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).cuda()
