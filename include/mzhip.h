@@ -261,8 +261,9 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
  * each simulation started from.  Same results as the separate calls.  For the CartPole network (pools of <= 8192 trees
  * with the default lanes per tree and max_simulations <= 62, so that 16 trees fit a workgroup's LDS) the whole run is ONE
  * launch: a workgroup keeps its 16 games from the first simulation to
- * the last, so no launch boundary, no host call and no other workgroup's data separates two simulations; other networks
- * and pools run it as the sequence of mz_infer_recurrent_step launches.  net and pool must use the same device and
+ * the last, so no launch boundary, no host call and no other workgroup's data separates two simulations; so it is for
+ * the Atari-shaped network (64 games a workgroup, pools of 18 actions); other networks and pools run it as the sequence
+ * of mz_infer_recurrent_step launches.  net and pool must use the same device and
  * stream. */
 int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
                            float* hidden_base, int32_t* parent_block, int64_t block_stride, int32_t* action,
@@ -302,7 +303,7 @@ typedef struct mz_move_io {
                                       its two launches (if it has two), [4s+2] after the tree step -- which shares the
                                       second launch for the TicTacToe network, so [4s+1]..[4s+2] spans head + tree step
                                       there; [4s+3] is unused.  A record costs ~13 us of stream time: sample sparsely.
-                                      Where mz_infer_recurrent_run is ONE launch (CartPole), only the events of the first
+                                      Where mz_infer_recurrent_run is ONE launch (CartPole, Atari-shaped), only the events of the first
                                       simulation that has any are recorded: [4s] before and [4s+1], [4s+2] after that launch,
                                       which holds all N simulations */
     /* Optional search trace (tests, debugging; every pointer NULL = off, all five non-NULL = on): what simulation s
@@ -316,8 +317,8 @@ typedef struct mz_move_io {
 } mz_move_io_t;
 
 /* make_move for every tree of the pool: initial_inference, root expansion (+noise), N simulations with the network in
- * the loop (mz_infer_recurrent_run), root statistics and action sampling -- 2N+5 (TicTacToe), N+4 (Atari-shaped) or 5
- * (CartPole, any N) launches on the stream, no host synchronisation.
+ * the loop (mz_infer_recurrent_run), root statistics and action sampling -- 2N+5 (TicTacToe) or 5 (CartPole,
+ * Atari-shaped: any N) launches on the stream, no host synchronisation.
  * io is checked against the handles (MZ_ERR_INVALID_ARG): num_trees == the pool's, num_simulations <= its max_simulations,
  * hidden_size and the action count == the network's, and pool, net and io->stream name one stream. */
 int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
