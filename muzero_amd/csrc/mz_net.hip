@@ -2147,7 +2147,7 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
                                            long block_stride, int* action, float* __restrict__ out_hidden,
                                            float* __restrict__ out_reward, float* __restrict__ out_value,
                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw,
-                                           const PoolDev& p, int nb, bool do_select = true) {
+                                           const PoolDev& p, int nb, bool do_select = true, bool keep_out = true) {
     constexpr int ROWS = 64;
     constexpr int TG = kAtariTreeG, TPB = TreeLds<TG>::kPB;
     static_assert(ROWS * TG == kThreadsW, "one pass of the workgroup covers its 64 trees");
@@ -2379,11 +2379,12 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < ROWS * 18; idx += kThreadsW) {
+    // keep_out = false: a later simulation of the same launch overwrites these rows (atari_run_kernel)
+    for (int idx = tid; keep_out && idx < ROWS * 18; idx += kThreadsW) {
         const int r = idx / 18, o = idx % 18;
         if (sRowOff[r] >= 0) out_logits[(size_t)(row0 + r) * 18 + o] = sOut[r][1 + o];
     }
-    if (tid < ROWS && sRowOff[tid] >= 0) {
+    if (keep_out && tid < ROWS && sRowOff[tid] >= 0) {
         out_value[row0 + tid] = sOut[tid][0];         // to_scalar is the identity (no support)
         if (out_value_raw) out_value_raw[row0 + tid] = sOut[tid][0];
         if (!INITIAL) out_reward[row0 + tid] = sOut[tid][19];
@@ -2443,7 +2444,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
         float* ov = out_value + (size_t)i * out_stride;
         float* ol = out_logits + (size_t)i * out_stride * 18;
         atari_body<false, 2>(w, p.T, hidden_base, parent_block, block_stride, action, oh, orw, ov, ol, nullptr, p, nb0 + i,
-                             i + 1 < nsim || final_select != 0);
+                             i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim);
         __syncthreads();
     }
 }
