@@ -2147,7 +2147,8 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
                                            long block_stride, int* action, float* __restrict__ out_hidden,
                                            float* __restrict__ out_reward, float* __restrict__ out_value,
                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw,
-                                           const PoolDev& p, int nb, bool do_select = true, bool keep_out = true) {
+                                           const PoolDev& p, int nb, bool do_select = true, bool keep_out = true,
+                                           LdsLog staged_log = nullptr) {
     constexpr int ROWS = 64;
     constexpr int TG = kAtariTreeG, TPB = TreeLds<TG>::kPB;
     static_assert(ROWS * TG == kThreadsW, "one pass of the workgroup covers its 64 trees");
@@ -2395,7 +2396,9 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
         // tree step of these 64 games (agent.py:208-211, then 177-190 for the next simulation): the tiles are free
         float* rows = reinterpret_cast<float*>(&sT[0][0]);
         double* s_log = reinterpret_cast<double*>(rows + ROWS * TreeLds<TG>::kRow);
-        const LdsLog lds_log = stage_log_table(p, s_log);                     // contains a barrier: the heads' reads of tD are over
+        // the log table: staged by the caller once for all its simulations (atari_run_kernel), or here, over the tiles
+        // (the barrier before the output stores has ended every read of them)
+        const LdsLog lds_log = staged_log != nullptr ? staged_log : stage_log_table(p, s_log);
         const float* mine = sOut[tid / TG];
         backprop_tree<TG, true, TPB>(p, tree, tree_active, tgl, nb, mine + 1, mine[19], mine[0], pf,
                                      rows + (tid / TG) * TreeLds<TG>::kRow);
@@ -2429,6 +2432,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
                                                                  int* action, float* out_reward, float* out_value,
                                                                  float* out_logits, long out_stride, int* trace_parent,
                                                                  int* trace_action) {
+    __shared__ double s_log_run[kLogLds];             // 2 log(n + 1): staged once for the whole run
+    const LdsLog run_log = stage_log_table(p, s_log_run);       // never nullptr here: the host checked N + 2 <= kLogLds
 #pragma unroll 1
     for (int i = 0; i < nsim; ++i) {
         asm volatile("" ::: "memory");
@@ -2444,7 +2449,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
         float* ov = out_value + (size_t)i * out_stride;
         float* ol = out_logits + (size_t)i * out_stride * 18;
         atari_body<false, 2>(w, p.T, hidden_base, parent_block, block_stride, action, oh, orw, ov, ol, nullptr, p, nb0 + i,
-                             i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim);
+                             i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim, run_log);
         __syncthreads();
     }
 }
