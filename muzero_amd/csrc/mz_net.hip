@@ -2433,24 +2433,38 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
                                                                  float* out_logits, long out_stride, int* trace_parent,
                                                                  int* trace_action) {
     __shared__ double s_log_run[kLogLds];             // 2 log(n + 1): staged once for the whole run
+    __shared__ int s_sel[2][64];                      // the selection between two simulations: leaf parents, actions
+    const int row0 = blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int b = row0 + threadIdx.x;
+        s_sel[0][threadIdx.x] = b < p.T ? parent_block[b] : -1;
+        s_sel[1][threadIdx.x] = b < p.T ? action[b] : -1;
+    }
     const LdsLog run_log = stage_log_table(p, s_log_run);       // never nullptr here: the host checked N + 2 <= kLogLds
+    // the body indexes both by game: game b of this workgroup is entry b - row0 of the LDS copies
+    int* const sel_parent = &s_sel[0][0] - row0;
+    int* const sel_action = &s_sel[1][0] - row0;
 #pragma unroll 1
     for (int i = 0; i < nsim; ++i) {
         asm volatile("" ::: "memory");
         if (trace_parent != nullptr && threadIdx.x < 64) {
-            const int b = blockIdx.x * 64 + threadIdx.x;
+            const int b = row0 + threadIdx.x;
             if (b < p.T) {
-                trace_parent[(size_t)i * p.T + b] = parent_block[b];
-                trace_action[(size_t)i * p.T + b] = action[b];
+                trace_parent[(size_t)i * p.T + b] = s_sel[0][threadIdx.x];
+                trace_action[(size_t)i * p.T + b] = s_sel[1][threadIdx.x];
             }
         }
         float* oh = hidden_base + (size_t)(nb0 + i) * block_stride;
         float* orw = out_reward + (size_t)i * out_stride;
         float* ov = out_value + (size_t)i * out_stride;
         float* ol = out_logits + (size_t)i * out_stride * 18;
-        atari_body<false, 2>(w, p.T, hidden_base, parent_block, block_stride, action, oh, orw, ov, ol, nullptr, p, nb0 + i,
+        atari_body<false, 2>(w, p.T, hidden_base, sel_parent, block_stride, sel_action, oh, orw, ov, ol, nullptr, p, nb0 + i,
                              i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim, run_log);
         __syncthreads();
+    }
+    if (final_select != 0 && threadIdx.x < 64 && row0 + threadIdx.x < p.T) {
+        parent_block[row0 + threadIdx.x] = s_sel[0][threadIdx.x];
+        action[row0 + threadIdx.x] = s_sel[1][threadIdx.x];
     }
 }
 
