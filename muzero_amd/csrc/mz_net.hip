@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     if ((rowmask >> (16 * m + n16)) & 1ull)
-                        __builtin_nontemporal_store(acc[m], reinterpret_cast<f32x4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol));
+                        *reinterpret_cast<f32x4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) = acc[m];
             }
             MZ_TRACE_NW(3);
         }
@@ -894,7 +894,10 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     constexpr int G = 16;
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
-    const int tid = threadIdx.x, row0 = blockIdx.x * 16;
+    // the 16 games of a block lie in the row block the job kernel ran on this block's XCD (blockIdx % 8): their partials
+    // are in this XCD's L2
+    const int xk = blockIdx.x >> 3;
+    const int tid = threadIdx.x, row0 = (((xk >> 2) * 8 + (blockIdx.x & 7)) * 4 + (xk & 3)) * 16;
     const int tree = row0 + tid / G, gl = tid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
@@ -3260,7 +3263,7 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
                       net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-    const int grid = (batch + 15) / 16;
+    const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
     if (with_select)
         ttt_head_step_kernel<true><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart, out_reward,
                                                               out_value, out_logits, parent_block, action);
