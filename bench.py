@@ -519,7 +519,7 @@ def main():
         if args.trees is None and args.lanes == 1:
             out['roofline']['rocprof'] = profiled_stats(args.workload, move.dominant)
         out.update(extra)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a one-GPU figure: the other ranks' processes share the host cores
             out['cpu_baseline'] = cpu_baseline(wl if with_net else dict(wl, net=None), args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
