@@ -320,3 +320,49 @@ def test_selfplay_engine_hot_reloads_published_weights(tmp_path):
     assert all(n.training_steps() == 250 for n in engine.search.networks)
     import numpy as np
     np.testing.assert_array_equal(engine.search.networks[1].get_weights(), cls(config, seed=2).get_weights())
+
+
+def test_device_tictactoe_env_matches_every_reference_transition():
+    """mz_env_ttt_step / mz_env_ttt_observe against the UNMODIFIED reference environment (games/tictactoe.py:71-148):
+    every reachable position x every legal move (tests/golden/ttt_env_transitions.npz, made by make_golden_env.py from
+    the reference itself), one game slot per transition, stepped directly through the C-ABI -- no host class in between."""
+    import os
+    import torch
+    from muzero_amd.exceptions import MuZeroEnvironmentError
+    from muzero_amd.vector_env import TicTacToeVectorEnv
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ttt_env_transitions.npz')))
+    K = len(fx['action'])
+    venv = TicTacToeVectorEnv(K)
+    venv.reset()
+    obs, legal, n_legal = venv.observe()
+    np.testing.assert_array_equal(obs.cpu().numpy(), np.broadcast_to(fx['reset_observation'], (K, 27)))
+    np.testing.assert_array_equal(legal.cpu().numpy(), np.broadcast_to(fx['reset_legal'], (K, 9)))
+    dev = venv.device
+    venv.board.copy_(torch.from_numpy(fx['board']).to(dev))
+    venv.to_play.copy_(torch.from_numpy(fx['to_play']).to(dev))
+    venv.steps.copy_(torch.from_numpy(fx['steps']).to(dev))
+    venv.ended.zero_()
+    reward = venv.step(torch.from_numpy(fx['action']).to(dev)).cpu().numpy().copy()
+    venv.check_illegal()
+    assert (venv.status.cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(reward, fx['reward'])
+    np.testing.assert_array_equal(venv.board.cpu().numpy(), fx['next_board'])
+    np.testing.assert_array_equal(venv.to_play.cpu().numpy(), fx['next_to_play'])
+    np.testing.assert_array_equal(venv.steps.cpu().numpy(), fx['next_steps'])
+    np.testing.assert_array_equal(venv.ended.cpu().numpy() != 0, fx['ended'] != 0)
+    obs, legal, n_legal = (x.cpu().numpy() for x in venv.observe())
+    np.testing.assert_array_equal(obs, fx['next_observation'])
+    np.testing.assert_array_equal(n_legal, fx['next_n_legal'])
+    np.testing.assert_array_equal(legal, fx['next_legal'])
+    # the moves the reference refuses (MuZeroEnvironmentError, games/tictactoe.py:122-123): status 2, state untouched
+    M = len(fx['illegal_action'])
+    venv = TicTacToeVectorEnv(M)
+    venv.reset()
+    venv.board.copy_(torch.from_numpy(fx['illegal_board']).to(dev))
+    venv.to_play.copy_(torch.from_numpy(fx['illegal_to_play']).to(dev))
+    venv.steps.copy_(torch.from_numpy((fx['illegal_board'] >= 0).sum(axis=1).astype(np.int32)).to(dev))
+    venv.step(torch.from_numpy(fx['illegal_action']).to(dev))
+    assert (venv.status.cpu().numpy() == 2).all()
+    np.testing.assert_array_equal(venv.board.cpu().numpy(), fx['illegal_board'])
+    with pytest.raises(MuZeroEnvironmentError):
+        venv.check_illegal()
