@@ -99,7 +99,8 @@ class SyntheticTreeMove:
             del self.logits, self.values, self.rewards
         torch.cuda.synchronize()
         self.hip_events = HipEvents()
-        self.event_sets = []
+        self.event_sets = []       # per sampled step: events around single fused-step launches
+        self.run_sets = []         # per sampled step: one event before the first fused step, one after the last
         self.trees_per_launch = Tl
 
     def counters(self):
@@ -117,9 +118,13 @@ class SyntheticTreeMove:
             events = None
             if timed_events and i == 0 and N > 1:     # HIP events around lane 0's fused steps, on its stream
                 events = (ctypes.c_void_p * (2 * (N - 1)))()
-                for s in range(self.event_stride // 2, N - 1, self.event_stride):       # a sample of the steps
-                    events[2 * s], events[2 * s + 1] = self.hip_events.new(), self.hip_events.new()
-                self.event_sets.append(events)
+                if timed_events == 'run':             # the N-1 fused steps as one bracket, no record between them
+                    events[0], events[2 * (N - 2) + 1] = self.hip_events.new(), self.hip_events.new()
+                    self.run_sets.append(events)
+                else:
+                    for s in range(self.event_stride // 2, N - 1, self.event_stride):       # a sample of the steps
+                        events[2 * s], events[2 * s + 1] = self.hip_events.new(), self.hip_events.new()
+                    self.event_sets.append(events)
             with torch.cuda.stream(l['stream']):
                 pool = l['pool']
                 pool.search_injected(l['logits'], l['rewards'], l['values'], noise=l['noise'], frac=0.25, logits=True,
@@ -138,6 +143,15 @@ class SyntheticTreeMove:
             for j in range(0, len(events), 2):
                 if events[j]:
                     ms.append(self.hip_events.elapsed_ms(ctypes.c_void_p(events[j]), ctypes.c_void_p(events[j + 1])))
+        return float(np.mean(ms)) * 1e-3 if ms else None
+
+    def run_durations(self):
+        """mean time (s) per fused step inside an un-evented run of N-1 of them (launch gaps included: an upper bound
+        of the kernel's duration)"""
+        import ctypes
+        N = self.wl['N']
+        ms = [self.hip_events.elapsed_ms(ctypes.c_void_p(ev[0]), ctypes.c_void_p(ev[2 * (N - 2) + 1])) / (N - 1)
+              for ev in self.run_sets]
         return float(np.mean(ms)) * 1e-3 if ms else None
 
 
@@ -229,7 +243,7 @@ class NetworkMove:
         from muzero_amd.games import atari_shaped, cartpole, tictactoe
         from muzero_amd.selfplay import LockstepSearch, PipelinedSearch, TrajectoryGather
         mod = {'tictactoe': tictactoe, 'cartpole': cartpole, 'atari': atari_shaped}[wl['net']]
-        self.wl = wl
+        self.wl, self.device = wl, device
         self.config = mod.make_config(num_simulations=wl['N'])
         self.net = self.config.network_config.network_class(self.config, seed=7)       # random-init (glorot) weights
         self.lanes = lanes
@@ -271,7 +285,12 @@ class NetworkMove:
         self.temperature = torch.ones(T, dtype=torch.float64, device=device)
         self.hooks = MoveEvents(wl['N'], event_stride)
         self.evals_per_launch = self.trees_per_launch
-        if self.dominant in ('cartpole16_run_kernel', 'atari_run_kernel'):
+        self.one_launch = self.dominant in ('cartpole16_run_kernel', 'atari_run_kernel', 'ttt_run_kernel')
+        self.launch_includes = {'cartpole16_run_kernel': 'the tree steps of all its simulations (trees in LDS)',
+                                'atari_run_kernel': 'the tree steps (expand, backup, next select) of all its simulations',
+                                'ttt_run_kernel': 'the prediction heads and tree steps of all its simulations'
+                                }.get(self.dominant)
+        if self.one_launch:
             # mz_search_move records the first sampled simulation's events around the whole run: one launch = N evaluations
             # of every game
             self.hooks.sampled = self.hooks.sampled[:1]
@@ -334,45 +353,144 @@ def host_cores():
     return max(1, min(visible, share) if share > 0 else visible)
 
 
-def cpu_baseline(wl, seconds, cores=None):
+class CpuBaseline:
     """The CPU oracle -- a port of the reference's Python MCTS (oracle/mcts_oracle.py) calling the numpy network port
     (oracle/net_oracle.py, float32, batch 1 per simulation like agent.py:204-207) -- one single-threaded process per host
     core (oracle/cpu_bench.py), same shapes, each for about `seconds`.  value = the sum of the workers'
-    rates.  Workloads without a network time the tree alone."""
-    import subprocess
-    cores = cores or host_cores()
-    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), '--actions', str(wl['A']), '--simulations',
-           str(wl['N']), '--players', str(wl['players']), '--discount', str(wl['discount']), '--default-value',
-           str(wl['default']), '--net', wl['net'] or 'none', '--seconds', str(seconds)]
-    if wl['bounds'] is not None:
-        cmd += ['--bounds', str(wl['bounds'][0]), str(wl['bounds'][1])]
-    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
-    procs = [subprocess.Popen(cmd + ['--seed', str(99 + i)], stdout=subprocess.PIPE, env=env, text=True)
-             for i in range(cores)]
-    rows = []
-    for pr in procs:
-        out, _ = pr.communicate(timeout=seconds * 10 + 120)
-        if pr.returncode != 0:
-            raise RuntimeError(f'cpu_baseline worker failed with {pr.returncode}')
-        rows.append(json.loads(out.strip().splitlines()[-1]))
-    rate = sum(r['simulations'] / r['seconds'] for r in rows)
-    moves = sum(r['moves'] for r in rows)
-    what = ('python tree oracle + numpy fp32 network oracle at batch 1' if wl['net'] else 'python tree oracle only')
-    return dict(value=rate, unit='simulations/s', cores=cores, kind='port', per_core=rate / cores,
-                sample=f"{moves} single-game moves x {wl['N']} simulations over {cores} single-threaded processes, "
-                       f"A={wl['A']}, {what}, {max(r['seconds'] for r in rows):.1f} s each")
+    rates.  Workloads without a network time the tree alone.
+
+    The workers are STARTED before this process makes its first HIP call (no child is ever forked from a process that
+    holds the GPU) and sit idle on their stdin; `collect()` releases them after the GPU's timed region, so they neither
+    share the host cores with the enqueueing thread nor run inside anyone's timing."""
+
+    def __init__(self, wl, seconds, cores=None):
+        import subprocess
+        self.wl, self.seconds, self.cores = wl, seconds, cores or host_cores()
+        cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), '--actions', str(wl['A']), '--simulations',
+               str(wl['N']), '--players', str(wl['players']), '--discount', str(wl['discount']), '--default-value',
+               str(wl['default']), '--net', wl['net'] or 'none', '--seconds', str(seconds), '--wait-for-go']
+        if wl['bounds'] is not None:
+            cmd += ['--bounds', str(wl['bounds'][0]), str(wl['bounds'][1])]
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        self.procs = [subprocess.Popen(cmd + ['--seed', str(99 + i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env,
+                                       text=True) for i in range(self.cores)]
+
+    def collect(self):
+        for pr in self.procs:                      # imports done: every worker is at its starting line
+            assert pr.stdout.readline().strip() == 'ready', 'cpu_baseline worker did not start'
+        for pr in self.procs:
+            pr.stdin.write('go\n')
+            pr.stdin.flush()
+        rows = []
+        for pr in self.procs:
+            out, _ = pr.communicate(timeout=self.seconds * 10 + 120)
+            if pr.returncode != 0:
+                raise RuntimeError(f'cpu_baseline worker failed with {pr.returncode}')
+            rows.append(json.loads(out.strip().splitlines()[-1]))
+        wl, cores = self.wl, self.cores
+        rate = sum(r['simulations'] / r['seconds'] for r in rows)
+        moves = sum(r['moves'] for r in rows)
+        what = ('python tree oracle + numpy fp32 network oracle at batch 1' if wl['net'] else 'python tree oracle only')
+        return dict(value=rate, unit='simulations/s', cores=cores, kind='port', per_core=rate / cores,
+                    sample=f"{moves} single-game moves x {wl['N']} simulations over {cores} single-threaded processes, "
+                           f"A={wl['A']}, {what}, {max(r['seconds'] for r in rows):.1f} s each")
+
+    def abandon(self):
+        for pr in self.procs:
+            pr.stdin.close()                       # readline() returns '' and the worker exits
+            pr.wait()
+
+
+def event_record_cost(hip_events, n=33):
+    """Stream time between two hipEventRecords with nothing between them (s, median of n): what every bracketed
+    duration below carries on top of the kernel it brackets, and what is subtracted from it."""
+    pairs = [(hip_events.record(), hip_events.record()) for _ in range(n)]
+    torch.cuda.synchronize()
+    return float(np.median([hip_events.elapsed_ms(a, b) for a, b in pairs])) * 1e-3
+
+
+def timed_region(move, steps, warmup, world, with_net, event_every=10, sync_every=0):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; the MAX over
+    ranks.  -> (seconds, simulations this rank backed up, sum of their path lengths)"""
+    import torch.distributed as dist
+    for i in range(warmup):
+        move.run(timed_events=(i == 0))              # the first warm-up step also warms the event-recording path
+    if with_net:
+        move.finish()
+        move.hooks.sets.clear()                      # warm-up timings are not reported
+    else:
+        move.event_sets.clear()
+        move.run_sets.clear()
+    torch.cuda.synchronize()
+    c0 = move.counters()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        # per-launch events on every event_every-th step; the tree-only moves bracket the run of fused steps on the next
+        move.run(timed_events=(i % event_every == 0) or ('run' if not with_net and i % event_every == 1 else False))
+        if sync_every and (i + 1) % sync_every == 0:
+            torch.cuda.synchronize()
+    if with_net:
+        move.finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    c1 = move.counters()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=move.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, int(c1[0] - c0[0]), int(c1[1] - c0[1])
+
+
+def tree_roofline_leg(name, device, steps, seed):
+    """The tree kernels alone (injected network outputs) at one of BASELINE.json's synthetic shapes: the
+    north star's HBM-roofline target is about THESE launches.  One native call enqueues a move; the fused step
+    (backup of simulation s + select of s+1) is the launch that repeats N-1 times."""
+    wl = dict(WORKLOADS[name])
+    stride = max(1, wl['N'] // 10)
+    move = SyntheticTreeMove(wl, device, seed, 1, stride)
+    move.hip_events.reserve(3 * (wl['N'] // stride + 2))
+    cost = event_record_cost(move.hip_events)
+    elapsed, sims, sum_d = timed_region(move, steps, 1, 1, False, event_every=max(2, steps))
+    assert sims == steps * wl['T'] * wl['N'], (sims, steps, wl)
+    mean_d = sum_d / sims
+    bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
+    pair = move.step_durations()
+    avg = max(pair - cost, 0.5 * pair)
+    in_run = move.run_durations()
+    traffic, traffic_src = measured_traffic(name, 'step_kernel')
+    out = {'workload': name, 'kernel': 'step_kernel', 'bound': 'hbm', 'trees': wl['T'], 'actions': wl['A'],
+           'simulations_per_move': wl['N'], 'steps': steps, 'bytes_per_launch': bytes_launch,
+           'avg_launch_us': avg * 1e6, 'event_pair_us': pair * 1e6, 'event_record_cost_us': cost * 1e6,
+           'us_per_step_in_run': None if in_run is None else in_run * 1e6,
+           'achieved_GBps': bytes_launch / avg / 1e9, 'peak_GBps': HBM_PEAK_GBS,
+           'frac': bytes_launch / avg / 1e9 / HBM_PEAK_GBS, 'mean_path_len': mean_d,
+           'simulations_per_sec': sims / elapsed, 'ms_per_move': elapsed / steps * 1e3,
+           'traffic': traffic, 'traffic_source': traffic_src}
+    for l in move.lanes:
+        l['pool'].close()
+    del move
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='tictactoe_4096x25', choices=sorted(WORKLOADS))
     ap.add_argument('--trees', type=int, default=None, help='override trees per GPU (profiling only)')
     ap.add_argument('--inject', action='store_true', help='tree kernels only, injected outputs (profiling only)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help='only the headline leg: no tree-kernel roofline legs, no 512-tree leg, no strong-scaling leg')
     ap.add_argument('--sync-every', type=int, default=0, help='synchronise the host every n timed steps (0 = never)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help="weak: the workload's games PER GPU (default); strong: the workload's games in total, sharded "
@@ -388,6 +506,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    wl = dict(WORKLOADS[args.workload])
+    if args.trees:
+        wl['T'] = args.trees
+    with_net = wl['net'] is not None and not args.inject
+    default_line = args.trees is None and args.lanes == 1 and not args.inject
+    extra_legs = default_line and not args.no_extra_legs and args.workload == 'tictactoe_4096x25'
+
+    # BEFORE the first HIP call: the CPU baseline's worker processes (a one-GPU figure: with more ranks their processes
+    # would share the host cores).  They idle until the GPU legs are over.
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu = CpuBaseline(wl if with_net else dict(wl, net=None), args.cpu_seconds)
+
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -397,70 +528,40 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
 
-    wl = dict(WORKLOADS[args.workload])
-    if args.trees:
-        wl['T'] = args.trees
+    full_T = wl['T']
     if args.scaling == 'strong' and world > 1:       # the same games in total, a contiguous shard per rank
         from muzero_amd.selfplay import shard_bounds
         lo, hi = shard_bounds(wl['T'], rank, world)
         wl['T'] = hi - lo
-    with_net = wl['net'] is not None and not args.inject
     # per-rank seeds: every rank searches different games
     stride = max(1, min(args.event_stride, wl['N'] // 4))
     move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride) if with_net
             else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
-
+    hip_events = move.hooks.ev if with_net else move.hip_events
     timed_steps = (args.steps + args.event_every - 1) // args.event_every + 1
-    (move.hooks.ev if with_net else move.hip_events).reserve(timed_steps * 3 * (wl['N'] // stride + 1))
-    for i in range(args.warmup):
-        move.run(timed_events=(i == 0))              # the first warm-up step also warms the event-recording path
-    if with_net:
-        move.finish()
-        move.hooks.sets.clear()                      # warm-up timings are not reported
-    else:
-        move.event_sets.clear()
-    torch.cuda.synchronize()
-    c0 = move.counters()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        move.run(timed_events=(i % args.event_every == 0))
-        if args.sync_every and (i + 1) % args.sync_every == 0:
-            torch.cuda.synchronize()
-    if with_net:
-        move.finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    c1 = move.counters()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    sims_rank = int(c1[0] - c0[0])
-    sum_d = int(c1[1] - c0[1])
+    hip_events.reserve(timed_steps * 3 * (wl['N'] // stride + 1) + 80)
+    record_cost = event_record_cost(hip_events)
+    elapsed, sims_rank, sum_d = timed_region(move, args.steps, args.warmup, world, with_net, args.event_every,
+                                             args.sync_every)
     assert sims_rank == args.steps * wl['T'] * wl['N'], (sims_rank, args.steps, wl['T'], wl['N'])
     total_sims = sims_rank
+    ranks_seen = 1
     if world > 1:                                    # ranks hold equal shards under weak scaling, near-equal under strong
-        tot = torch.tensor([sims_rank], dtype=torch.int64, device=device)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_sims = int(tot.item())
+        tot = torch.tensor([sims_rank, 1], dtype=torch.int64, device=device)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)   # [1]: an all-reduce of ones = the ranks RCCL really connected
+        total_sims, ranks_seen = int(tot[0].item()), int(tot[1].item())
     mean_d = sum_d / sims_rank
     tree_bytes_launch = move.trees_per_launch * bytes_per_simulation(wl['A'], mean_d, wl['A'])
+    uncost = lambda t: None if t is None else max(t - record_cost, 0.5 * t)     # a bracketed duration without its record
     extra = {}
     # every network kernel but CartPole's large-batch one (batches > 8192) computes in split-f16 arithmetic
     split_f16 = with_net and not (wl['net'] == 'cartpole' and wl['T'] > 8192)
     if with_net:
-        k1, rest = move.hooks.durations()
+        k1_raw, rest_raw = move.hooks.durations()
+        k1, rest = uncost(k1_raw), uncost(rest_raw)
         flops_launch = move.evals_per_launch * move.flops_per_eval
         achieved = flops_launch / k1 / 1e12
-        traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
-                                else (None, None))
+        traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if default_line else (None, None))
         if split_f16:
             # The kernel multiplies on f16 MFMA with every f32 operand split in two halfs: three f16 MFMA products
             # per algorithmic product, held to the f32 tolerance.  Priced against the f16 peak the instructions run at;
@@ -471,17 +572,16 @@ def main():
         roofline = {'bound': 'mfma', 'kernel': move.dominant, 'achieved': achieved, 'peak': peak,
                     'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
-                    'avg_launch_us': k1 * 1e6, 'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
+                    'avg_launch_us': k1 * 1e6, 'event_pair_us': k1_raw * 1e6, 'event_record_cost_us': record_cost * 1e6,
+                    'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
                     'executed_mfma_tflops': executed, 'executed_frac': executed / peak}
-        rest_name = ('head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else
-                     'after_fused_kernel_us' if move.dominant in ('cartpole16_run_kernel', 'atari_run_kernel') else
-                     'tree_step_kernel_us')
-        if move.dominant in ('cartpole16_run_kernel', 'atari_run_kernel'):
+        one_launch = move.one_launch
+        rest_name = ('after_fused_kernel_us' if one_launch else
+                     'head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else 'tree_step_kernel_us')
+        if one_launch:
             roofline['simulations_per_launch'] = wl['N']
             roofline['us_per_simulation'] = k1 * 1e6 / wl['N']
-            roofline['launch_includes'] = ('the tree steps of all its simulations (trees in LDS)'
-                                           if move.dominant == 'cartpole16_run_kernel' else
-                                           'the tree steps (expand, backup, next select) of all its simulations')
+            roofline['launch_includes'] = move.launch_includes
         extra = {rest_name: rest * 1e6, 'tree_algorithmic_bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d,
                  'recurrent_inference_evals_per_sec': total_sims / elapsed}
         if rest_name == 'tree_step_kernel_us':       # the tree step is a launch of its own: its HBM roofline beside it
@@ -490,18 +590,52 @@ def main():
                                            'frac': tree_bytes_launch / rest / 1e9 / HBM_PEAK_GBS, 'avg_launch_us': rest * 1e6}
         network = f"{wl['net']} network, random-init weights, f32 results (1e-5 of the fp64 oracle)"
     else:
-        avg = move.step_durations()
+        pair = move.step_durations()
+        avg = uncost(pair)
+        in_run = move.run_durations()
         achieved = tree_bytes_launch / avg / 1e9
         traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
                                 else (None, None))
         roofline = {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
-                    'avg_launch_us': avg * 1e6,
+                    'avg_launch_us': avg * 1e6, 'event_pair_us': pair * 1e6, 'event_record_cost_us': record_cost * 1e6,
+                    'us_per_step_in_run': None if in_run is None else in_run * 1e6,
                     'bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d}
         # all lanes together: algorithmic bytes of every simulation of the timed region over its wall time
         extra = {'aggregate_algorithmic_GBps': sims_rank * bytes_per_simulation(wl['A'], mean_d, wl['A']) / elapsed / 1e9}
         network = 'injected outputs (tree kernels only)'
+
+    # ---- further legs of the default line (outside the headline's timed region)
+    if extra_legs:
+        del move
+        torch.cuda.empty_cache()
+        if world == 1:
+            # the tree kernels' HBM roofline at BASELINE configs[3] and [4] (tree half), where the driver sees it
+            extra['tree_roofline'] = [tree_roofline_leg('atari_16384x50', device, 6, 4321),
+                                      tree_roofline_leg('go_2048x800', device, 3, 4322)]
+            # one rank's shard of configs[2] read as strong scaling over 8 GPUs: 512 games on this one GPU
+            small = dict(wl, T=512)
+            mv = NetworkMove(small, device, 77, 1, 1, stride)
+            mv.hooks.ev.reserve(8)
+            el, sm, _ = timed_region(mv, 40, 5, 1, True, event_every=1 << 30)
+            extra['strong_scaling_proxy'] = {'trees': 512, 'simulations_per_sec': sm / el, 'ms_per_move': el / 40 * 1e3,
+                                             'note': 'one GPU searching the 512 games an 8-GPU strong-scaling run of '
+                                                     '4096 games gives each rank'}
+            del mv
+        else:
+            # the other reading of configs[2]: the SAME 4096 games sharded over the ranks (strong scaling)
+            from muzero_amd.selfplay import shard_bounds
+            lo, hi = shard_bounds(full_T, rank, world)
+            mv = NetworkMove(dict(wl, T=hi - lo), device, 4000 + rank, world, 1, stride)
+            mv.hooks.ev.reserve(8)
+            el, sm, _ = timed_region(mv, args.steps, args.warmup, world, True, event_every=1 << 30)
+            tot = torch.tensor([sm], dtype=torch.int64, device=device)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            extra['strong_scaling'] = {'trees_total': full_T, 'trees_per_gpu': hi - lo,
+                                       'simulations_per_sec': int(tot.item()) / el, 'ms_per_step': el / args.steps * 1e3}
+            del mv
+        torch.cuda.empty_cache()
 
     if rank == 0:
         out = {
@@ -513,15 +647,18 @@ def main():
                        'actions': wl['A'],
                        'simulations_per_move': wl['N'], 'network': network,
                        'sharding': f'{world} independent game shards (one rank per GPU)' +
-                                   (', per-move all-gather of search statistics' if world > 1 and with_net else '')},
+                                   (', per-move all-gather of search statistics' if world > 1 and with_net else ''),
+                       'ranks_in_all_reduce': ranks_seen},
             'roofline': roofline,
         }
-        if args.trees is None and args.lanes == 1:
-            out['roofline']['rocprof'] = profiled_stats(args.workload, move.dominant)
+        if default_line:
+            out['roofline']['rocprof'] = profiled_stats(args.workload, roofline['kernel'])
         out.update(extra)
-        if not args.no_cpu_baseline and world == 1:  # a one-GPU figure: the other ranks' processes share the host cores
-            out['cpu_baseline'] = cpu_baseline(wl if with_net else dict(wl, net=None), args.cpu_seconds)
+        if cpu is not None:
+            out['cpu_baseline'] = cpu.collect()
         print(json.dumps(out))
+    elif cpu is not None:
+        cpu.abandon()
     if world > 1:
         dist.destroy_process_group()
 

@@ -331,8 +331,10 @@ int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
  *                                  (logits when is_logits != 0, see mz_expand_backprop_logits)
  *   reward, value [N+1, T] f32 device (row 0 unused); legal/n_legal as mz_expand_roots; noise as mz_add_root_noise
  *   parent_block, action [T] i32 device workspaces (the last select's outputs)
- *   events: NULL, or HOST array of 2*(N-1) hipEvent_t; step s (1-based) with events[2(s-1)] != NULL is bracketed by
- *           events[2(s-1)] and events[2(s-1)+1] (measurement only; sample sparsely, a record costs stream time) */
+ *   events: NULL, or HOST array of 2*(N-1) hipEvent_t; a non-NULL events[2(s-1)] is recorded before fused step s
+ *           (1-based), a non-NULL events[2(s-1)+1] after it, independently of each other: a pair times one launch, the
+ *           'before' of step 1 with the 'after' of step N-1 times the whole run of steps without a record in between
+ *           (measurement only; a record costs stream time) */
 int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations, const float* policy, int32_t is_logits,
                             const float* reward, const float* value, const int32_t* legal, const int32_t* n_legal,
                             const double* noise, double noise_frac, int32_t* parent_block, int32_t* action,

@@ -119,11 +119,14 @@ extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations,
             MZ_TRY_(is_logits ? mz_expand_backprop_logits(pool, pol, rw, vl) : mz_expand_backprop(pool, pol, rw, vl));
             break;
         }
-        const bool timed = events && events[2 * (s - 1)];      // a step whose events are NULL is not timed
-        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1)]), pool->stream));
+        // events[2(s-1)] is recorded before fused step s, events[2(s-1)+1] after it; either may be NULL (a pair around one
+        // step times that launch, a 'before' of the first step and an 'after' of the last one time the run of them)
+        if (events && events[2 * (s - 1)])
+            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1)]), pool->stream));
         MZ_TRY_(is_logits ? mz_step_logits(pool, pol, rw, vl, parent_block, action)
                           : mz_step(pool, pol, rw, vl, parent_block, action));
-        if (timed) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1) + 1]), pool->stream));
+        if (events && events[2 * (s - 1) + 1])
+            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (s - 1) + 1]), pool->stream));
     }
 #undef MZ_TRY_
     return MZ_OK;

@@ -143,8 +143,20 @@ class Network:
     ACTION_SPACE_SIZE = 0
     VALUE_RAW = 1          # width of the un-scalarised value head
 
+    # the layer sizes the HIP kernels implement, under the names the reference's network classes take them by
+    # (games/tictactoe.py:156-161, games/cartpole.py:68-74); None = the reference class has no such parameter
+    SIZES = {'hidden_state_size': 128, 'hidden_size': 128, 'support_size': None}
+
     def __init__(self, config, weights: Optional[np.ndarray] = None, seed: int = 0, training_steps: int = 0,
-                 device='cuda', **_unused_reference_parameters) -> None:
+                 device='cuda', regularizer=None, **size_parameters) -> None:
+        # `regularizer` only matters to training (reference network classes hand it to Keras); the sizes select the
+        # architecture, and the kernels implement exactly one: anything else is refused, never silently replaced
+        for name, value in size_parameters.items():
+            if name not in self.SIZES:
+                raise MuZeroError(f'{type(self).__name__}: unknown network parameter {name!r}')
+            if value != self.SIZES[name]:
+                raise MuZeroError(f'{type(self).__name__}: {name}={value!r} is not implemented by the HIP kernels '
+                                  f'(they are built for {name}={self.SIZES[name]!r})')
         self.config = config
         self._h = None
         self._lib = _lib.load()
@@ -416,6 +428,7 @@ class CartPoleNetwork(Network):
     HIDDEN_SHAPE = (1, 128)
     ACTION_SPACE_SIZE = 2
     VALUE_RAW = 101
+    SIZES = {'hidden_state_size': 128, 'hidden_size': 128, 'support_size': 100}
 
 
 class AtariShapedNetwork(Network):

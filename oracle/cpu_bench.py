@@ -72,7 +72,14 @@ def main():
     ap.add_argument('--net', default='none', choices=['none', 'tictactoe', 'cartpole', 'atari'])
     ap.add_argument('--seconds', type=float, default=10.0)
     ap.add_argument('--seed', type=int, default=99)
+    ap.add_argument('--wait-for-go', action='store_true',
+                    help='start measuring only when a line arrives on stdin (bench.py starts its workers before it touches '
+                         'the GPU and releases them after the GPU timed region)')
     a = ap.parse_args()
+    if a.wait_for_go:
+        print('ready', flush=True)
+        if not sys.stdin.readline():
+            return                                   # the parent went away
     sims, moves, dt = run(a.actions, a.simulations, a.players, a.discount, a.default_value,
                           None if a.bounds is None else tuple(a.bounds), a.net, a.seconds, a.seed)
     print(json.dumps(dict(simulations=sims, moves=moves, seconds=dt)))

@@ -1,8 +1,9 @@
 """BASELINE.json's configurations at their FULL sizes on the GPU, held to the same bar as the small cases.
 
-* the native move (mz_search_move: the fused kernels of the bench line) at 4096 x 25 TicTacToe, 1024 x 50 CartPole and
-  16384 x 50 Atari-shaped games with the network in the loop: its per-simulation trace (mz_move_io_t.trace_*) of a
-  sample of trees is replayed through the plain-C oracle -- selections, visit counts, root values, policies and chosen
+* the native move (mz_search_move: the fused kernels of the bench line) at 4096 x 25 and 512 x 25 TicTacToe (512 = one
+  rank's shard of BASELINE configs[2] at 8 GPUs), 1024 x 50 CartPole and 16384 x 50 Atari-shaped games with the network
+  in the loop: its per-simulation trace (mz_move_io_t.trace_*) of EVERY live tree (Atari shape: 1024 of them) is
+  replayed through the plain-C oracle -- selections, visit counts, root values, policies and chosen
   actions bit for bit, ZERO mismatches -- the network outputs in the trace are checked against the fp64 network oracle
   (1e-5), and size-independent properties are checked on every tree;
 * the tree kernels alone at 16384 x 18 x 50 (unknown bounds) and 2048 x 362 x 800 (Go-shaped: 801 records per tree, an
@@ -24,8 +25,11 @@ def _decode_hidden(game, hidden):
     return (img[:, 0] + img[:, 1] / 2048.0).reshape(hidden.shape).cpu().numpy()
 
 
-@pytest.mark.parametrize('game,T,N', [('tictactoe', 4096, 25), ('cartpole', 1024, 50), ('atari', 16384, 50)])
-def test_native_move_full_size_against_the_oracles(game, T, N):
+# replayed: how many live trees go through the C oracle (None = every one of them; the Atari shape reads 50 records of
+# a tree back one call at a time, so it keeps a sample)
+@pytest.mark.parametrize('game,T,N,replayed', [('tictactoe', 4096, 25, None), ('tictactoe', 512, 25, None),
+                                               ('cartpole', 1024, 50, None), ('atari', 16384, 50, 1024)])
+def test_native_move_full_size_against_the_oracles(game, T, N, replayed):
     import torch
     from muzero_amd.games import atari_shaped, cartpole, tictactoe
     from muzero_amd.selfplay import LockstepSearch
@@ -75,8 +79,8 @@ def test_native_move_full_size_against_the_oracles(game, T, N):
     if kb is None:
         assert (minmax[live, 0] <= minmax[live, 1]).all()
 
-    # ---- a sample of trees replayed through the C oracle with the device's own outputs: zero mismatches
-    sample = np.concatenate([rows[:8], rng.choice(rows[8:], size=56, replace=False)])
+    # ---- the trees replayed through the C oracle with the device's own outputs: zero mismatches
+    sample = rows if replayed is None else np.concatenate([rows[:8], rng.choice(rows[8:], size=replayed - 8, replace=False)])
     S = len(sample)
     opool = c_oracle.OraclePool(S, A, N, config.game_config.num_players, config.game_config.discount,
                                 config.mcts_config.default_value, None if kb is None else kb.endpoints())
@@ -102,6 +106,7 @@ def test_native_move_full_size_against_the_oracles(game, T, N):
     np.testing.assert_array_equal(chosen[sample], opool.select_action(u[sample], 1.0))
 
     # ---- the network outputs of the trace against the fp64 network oracle, from the workspace's own parent rows
+    sample = sample[:64] if len(sample) <= 64 else np.concatenate([sample[:8], rng.choice(sample[8:], size=56, replace=False)])
     hidden = _decode_hidden(game, search.hidden)
     vs = 100.0 if game == 'cartpole' else 1.0
     h0, _, l0, _ = ref.initial_inference(obs[sample])

@@ -594,3 +594,88 @@ def test_pipelined_lanes_equal_one_lockstep_search(lanes):
         for x, y in zip(a, b):
             assert torch.equal(x[active], y[active])
     assert piped.counters()[0] == 2 * int(active.sum()) * N
+
+
+def test_integration_section_1_verbatim_with_the_hip_network():
+    """INTEGRATION.md section 1 as written: MCTSAgent(config, config.make_uniform_network(), ...).play_game(...) -- one
+    game, 25 simulations per move, the HIP network called at batch 1 like the reference calls its network
+    (agent.py:204-207, BASELINE configs[0]'s shape on the product path).  Every network call is recorded; each move's
+    tree is then replayed through the C oracle with those outputs (selections, policy, root value and sampled action
+    bit for bit) and the outputs themselves are held to the fp64 network oracle at 1e-5."""
+    import random
+    import torch
+    from muzero_amd.agent import MCTSAgent
+    from muzero_amd.games.tictactoe import make_config
+    from oracle import c_oracle, net_oracle
+    N = 25
+    config = make_config(num_simulations=N)
+    network = config.make_uniform_network()           # HIP-backed TicTacToeNetwork
+    agent = MCTSAgent(config, network, 'a0')
+    calls = []
+    initial, recurrent = network.initial_inference, network.recurrent_inference
+
+    def rec_initial(observation):
+        out = initial(observation)
+        calls.append(('initial', np.asarray(torch.as_tensor(observation).cpu(), np.float32).reshape(1, 27), None, out))
+        return out
+
+    def rec_recurrent(hidden_state, action):
+        out = recurrent(hidden_state, action)
+        calls.append(('recurrent', torch.as_tensor(hidden_state).cpu().numpy().reshape(1, 1152).copy(),
+                      int(np.asarray(action).reshape(-1)[0]), out))
+        return out
+
+    network.initial_inference, network.recurrent_inference = rec_initial, rec_recurrent
+    np.random.seed(1234)
+    random.seed(1234)
+    history = agent.play_game(config.create_environment())
+    moves = len(history)
+    assert 5 <= moves <= 9 and len(calls) == moves * (N + 1)
+    assert history.metadata['agent_id'] == 'a0' and history.metadata['network_id'] == '0'
+
+    ref = net_oracle.make_oracle('tictactoe', network.get_weights())
+    env = config.create_environment()
+    state = env.reset()
+    np.random.seed(1234)
+    random.seed(1234)
+    kb = config.value_config.known_bounds.endpoints()
+    for m in range(moves):
+        mc = calls[m * (N + 1):(m + 1) * (N + 1)]
+        assert mc[0][0] == 'initial' and all(c[0] == 'recurrent' for c in mc[1:])
+        np.testing.assert_array_equal(mc[0][1].reshape(3, 3, 3), np.asarray(state.observation, np.float32))
+        outs = [c[3].split_batch()[0] for c in mc]
+        hidden = [o.hidden_state.cpu().numpy().reshape(1, 1152) for o in outs]
+        # -- the network against the fp64 oracle
+        h0, v0, l0, _ = ref.initial_inference(mc[0][1])
+        np.testing.assert_allclose(hidden[0], h0, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(outs[0].value, v0[0], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(outs[0].policy_logits.cpu().numpy(), l0[0], rtol=1e-5, atol=1e-5)
+        # -- the tree through the C oracle, fed the device's outputs
+        legal = list(state.legal_actions)
+        opool = c_oracle.OraclePool(1, 9, N, 2, config.game_config.discount, config.mcts_config.default_value, kb)
+        lg = np.zeros((1, 9), np.int32)
+        lg[0, :len(legal)] = legal
+        opool.expand_roots(outs[0].masked_policy(legal).reshape(1, 9), lg, np.array([len(legal)], np.int32))
+        noise = np.zeros((1, 9))
+        noise[0, :len(legal)] = np.random.dirichlet([config.mcts_config.root_dirichlet_alpha] * len(legal))
+        opool.add_root_noise(noise, config.mcts_config.root_exploration_fraction)
+        for s in range(N):
+            pb, a = opool.select()
+            kind, hid_in, act_in, _ = mc[s + 1]
+            assert act_in == int(a[0]), f'move {m} simulation {s}: action'
+            np.testing.assert_array_equal(hid_in, hidden[int(pb[0])], err_msg=f'move {m} simulation {s}: parent state')
+            o = outs[s + 1]
+            h2, r2, v2, l2, _ = ref.recurrent_inference(hid_in, np.array([act_in]))
+            np.testing.assert_allclose(hidden[s + 1], h2, rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose([o.reward, o.value], [r2[0], v2[0]], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(o.policy_logits.cpu().numpy(), l2[0], rtol=1e-5, atol=1e-5)
+            opool.expand_backprop(o.masked_policy(list(range(9))).reshape(1, 9), np.array([o.reward], np.float32),
+                                  np.array([o.value], np.float32))
+        _, root_value, _, policy = opool.root_stats()
+        assert history.root_values[m] == root_value[0]
+        np.testing.assert_array_equal(np.asarray(history.policies[m], np.float32), policy[0])
+        u = random.random()                               # random.choices consumes one uniform per sampled action
+        assert history.actions[m] == int(opool.select_action(np.array([u]), 1.0)[0])
+        state, reward, done, _ = env.step(int(history.actions[m]))
+        assert reward == history.rewards[m]
+    assert done
