@@ -26,7 +26,7 @@ def load_golden(name):
         return {k: data[k] for k in data.files}
 
 
-TREE_FIXTURES = [n for n in golden_names() if not n.startswith(('ttt_game', 'replay_'))]
+TREE_FIXTURES = [n for n in golden_names() if not n.startswith(('ttt_game', 'replay_', 'ttt_env_'))]
 REPLAY_FIXTURES = golden_names('replay_')
 GAME_FIXTURES = golden_names('ttt_game')
 
