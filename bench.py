@@ -239,13 +239,17 @@ class NetworkMove:
     reference path of MCTSAgent.make_move, batched."""
     bound = 'mfma'
 
-    def __init__(self, wl, device, seed, world, lanes=1, event_stride=5):
+    def __init__(self, wl, device, seed, world, lanes=1, event_stride=5, run_mode=0, job_rows=0):
         from muzero_amd.games import atari_shaped, cartpole, tictactoe
         from muzero_amd.selfplay import LockstepSearch, PipelinedSearch, TrajectoryGather
         mod = {'tictactoe': tictactoe, 'cartpole': cartpole, 'atari': atari_shaped}[wl['net']]
         self.wl, self.device = wl, device
         self.config = mod.make_config(num_simulations=wl['N'])
         self.net = self.config.network_config.network_class(self.config, seed=7)       # random-init (glorot) weights
+        if run_mode:                                  # A/B measurements only (Network.set_run_mode)
+            self.net.set_run_mode(run_mode)
+        if job_rows:
+            self.net.set_job_rows(job_rows)
         self.lanes = lanes
         if lanes > 1:
             self.search = PipelinedSearch(self.config, self.net, num_trees=wl['T'], lanes=lanes, device=device)
@@ -262,10 +266,15 @@ class NetworkMove:
             cells = torch.randint(0, 3, (T, 9), generator=g, device=device)
             to_play = torch.randint(0, 2, (T, 1), generator=g, device=device).expand(T, 9)
             self.obs = torch.stack([(cells == 0), (cells == 1), to_play.bool()], -1).float().reshape(T, 27).contiguous()
-            self.dominant = 'ttt_ring_kernel'
-            # SURVEY.md 8(d) terms this kernel covers per evaluation: conv 49*137*128, dense 9*128*128,
-            # reward 1152, prediction conv 9*128*128 (multiply-adds x2)
-            self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
+            # the N simulations of a move are ONE launch, ttt_run_kernel (mz_infer_recurrent_run): the jobs
+            # (conv 49*137*128, dense 9*128*128, reward 1152, prediction conv 9*128*128), the head (dense 128*128, value
+            # 128, policy 9*128) -- SURVEY.md 8(d)'s 2.35 MFLOP per evaluation, multiply-adds x2 -- and the tree steps
+            self.dominant = 'ttt_run_kernel'
+            self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128 + 128 * 128 + 128 + 9 * 128)
+            if run_mode == 2 or (job_rows or (16 if wl['T'] <= 1792 else 64)) == 16:
+                # a launch per simulation (A/B runs; batches of 16-game jobs): the job kernel and its terms alone
+                self.dominant = 'ttt_ring_kernel'
+                self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
         elif wl['net'] == 'atari':       # synthetic (2,128) observations
             self.obs = torch.randn(T, 256, generator=g, device=device).contiguous()
             # the N simulations of a move (whole network + tree step of a workgroup's 64 games, looped in the kernel) are ONE
@@ -491,6 +500,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true',
                     help='only the headline leg: no tree-kernel roofline legs, no 512-tree leg, no strong-scaling leg')
+    ap.add_argument('--run-mode', type=int, default=0,
+                    help='TicTacToe A/B measurements: 1 = the one-launch move with agent-scope fences, 2 = a launch per '
+                         'simulation (Network.set_run_mode)')
+    ap.add_argument('--job-rows', type=int, default=0, choices=[0, 16, 64],
+                    help='TicTacToe A/B measurements: games per workgroup of the job kernel (Network.set_job_rows)')
     ap.add_argument('--sync-every', type=int, default=0, help='synchronise the host every n timed steps (0 = never)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help="weak: the workload's games PER GPU (default); strong: the workload's games in total, sharded "
@@ -510,7 +524,8 @@ def main():
     if args.trees:
         wl['T'] = args.trees
     with_net = wl['net'] is not None and not args.inject
-    default_line = args.trees is None and args.lanes == 1 and not args.inject
+    default_line = (args.trees is None and args.lanes == 1 and not args.inject and args.run_mode == 0 and
+                    args.job_rows == 0)
     extra_legs = default_line and not args.no_extra_legs and args.workload == 'tictactoe_4096x25'
 
     # BEFORE the first HIP call: the CPU baseline's worker processes (a one-GPU figure: with more ranks their processes
@@ -535,7 +550,7 @@ def main():
         wl['T'] = hi - lo
     # per-rank seeds: every rank searches different games
     stride = max(1, min(args.event_stride, wl['N'] // 4))
-    move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride) if with_net
+    move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride, args.run_mode, args.job_rows) if with_net
             else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
     hip_events = move.hooks.ev if with_net else move.hip_events
     timed_steps = (args.steps + args.event_every - 1) // args.event_every + 1

@@ -205,6 +205,20 @@ int mz_net_status(mz_net_t* net, int32_t* out_flags_host);
  * inference call that consists of two launches (TicTacToe: per-cell kernel, then head kernel) records it on the
  * stream between them, so a caller bracketing the call with its own events can time each kernel. NULL disables. */
 int mz_net_set_mid_event(mz_net_t* net, void* hip_event);
+/* Test / measurement switches of mz_infer_recurrent_run for the TicTacToe network (no counterpart in the reference; the
+ * library itself never changes them): mode 0 (default) = all simulations in one launch where the pool allows it; 1 = the
+ * same launch with full agent-scope fences at every meeting of a row block's workgroups (the path taken by itself when
+ * they are found on different XCDs); 2 = a launch per simulation (the kernels of mz_infer_recurrent_step).  All three
+ * give bit-identical trees and outputs.
+ * mz_debug_run_info: out2_host[0] = row-block runs that took the fence path since the handle was created, [1] = row-block
+ * runs in all.  Synchronises. */
+int mz_debug_set_run_mode(mz_net_t* net, int32_t mode);
+/* Test / measurement switch of the TicTacToe job kernel's shape: rows = 0 (default) chooses by batch size -- 16 games x one
+ * board cell per workgroup up to 1792 games, 64 games x a group of cells beyond --, 16 or 64 force that shape.  The two
+ * shapes sum the prediction conv's per-cell terms in different orders: results agree to float rounding (both are held to
+ * 1e-5 of the fp64 oracle), not bit for bit. */
+int mz_debug_set_job_rows(mz_net_t* net, int32_t rows);
+int mz_debug_run_info(mz_net_t* net, int64_t* out2_host);
 
 /* Network.initial_inference (network.py:221-229) fused with split_batch's to_scalar (network.py:165-174).
  *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4, Atari-shaped 256 = 2x128);
@@ -262,8 +276,10 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
  * with the default lanes per tree and max_simulations <= 62, so that 16 trees fit a workgroup's LDS) the whole run is ONE
  * launch: a workgroup keeps its 16 games from the first simulation to
  * the last, so no launch boundary, no host call and no other workgroup's data separates two simulations; so it is for
- * the Atari-shaped network (64 games a workgroup, pools of 18 actions); other networks and pools run it as the sequence
- * of mz_infer_recurrent_step launches.  net and pool must use the same device and
+ * the Atari-shaped network (64 games a workgroup, pools of 18 actions), and for the TicTacToe network with the default
+ * 16 lanes per tree (the four workgroups of 64 games stay resident and hand each other their results through their XCD's
+ * L2 twice per simulation; if that ever fails to complete within a second the launch gives up and mz_pool_counters
+ * reports MZ_ERR_HIP); other networks and pools run it as the sequence of mz_infer_recurrent_step launches.  net and pool must use the same device and
  * stream. */
 int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
                            float* hidden_base, int32_t* parent_block, int64_t block_stride, int32_t* action,

@@ -91,6 +91,9 @@ PROTOTYPES = {
     'mz_net_training_steps': (c_int64, [c_void_p]),
     'mz_net_status': (ctypes.c_int, [c_void_p, c_void_p]),
     'mz_net_set_mid_event': (ctypes.c_int, [c_void_p, c_void_p]),
+    'mz_debug_set_run_mode': (ctypes.c_int, [c_void_p, c_int32]),
+    'mz_debug_run_info': (ctypes.c_int, [c_void_p, c_void_p]),
+    'mz_debug_set_job_rows': (ctypes.c_int, [c_void_p, c_int32]),
     'mz_infer_initial': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_infer_recurrent_step': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -174,7 +174,8 @@ struct TttDev {
     const float* pred_conv_s;   // [9 cells]
     int job_cells[4][3];        // the cells of job j, -1 = none
     const int4* ring_desc;      // the jobs as stages of ttt_ring_kernel: (kind, cell, weight matrix, source cell)
-    int ring_first[5];          // job j owns descriptors [ring_first[j], ring_first[j+1])
+    int ring_first[15];         // job j owns descriptors [ring_first[j], ring_first[j+1]): j = 0..3 the four cell groups of
+                                // the 64-game workgroups, j = 5 + c the single cell c of the 16-game workgroups
     float dyn_reward_b, pred_value_b;
     int* range_flag;            // raised when a kernel splits a value outside the split-f16 domain (mz_net_status)
 };
@@ -232,14 +233,41 @@ __device__ __forceinline__ void note_range(float vmax, int* range_flag) {
 }
 
 // acc += acx / 2048: the cross terms of a split-f16 accumulation join the h x h terms once, at its end
-__device__ __forceinline__ void fold4(f32x4 (&acc)[4], const f32x4 (&acx)[4]) {
+template <int MB>
+__device__ __forceinline__ void fold4(f32x4 (&acc)[MB], const f32x4 (&acx)[MB]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] += acx[m] * kUnsplit;
+    for (int m = 0; m < MB; ++m) acc[m] += acx[m] * kUnsplit;
 }
 
-__device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
+template <int MB>
+__device__ __forceinline__ void zero4(f32x4 (&acc)[MB]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MB; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// A load that is never served from this CU's L1 (agent scope: `sc1`; tools/micro/inv_probe2.hip: it returns what another
+// CU of the XCD has stored, at the latency of an L2 hit, where a plain load returns the L1's stale line and
+// `buffer_inv sc0` drops nothing).  Everything one workgroup of a row block reads of what another one wrote DURING the
+// launch and may have cached before -- partials, reward partials, selections -- is read this way; hidden rows are written
+// once per launch and read only afterwards, so no CU can hold an older copy of them.
+template <bool COH>
+__device__ __forceinline__ float4 load4(const float4* p) {
+    if (!COH) return *p;
+    // 16 bytes in one instruction: the `nt` load misses the L1 like the `sc1` one (same probe), and the fence path's
+    // `buffer_inv sc1` covers it where the workgroups are on different XCDs
+    typedef float __attribute__((ext_vector_type(4))) v4;
+    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <bool COH>
+__device__ __forceinline__ float load1(const float* p) {
+    if (!COH) return *p;
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COH>
+__device__ __forceinline__ int load1(const int* p) {
+    if (!COH) return *p;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the TicTacToe job kernel
@@ -276,10 +304,10 @@ __device__ __forceinline__ void load_bw(BFragW& b, const float* __restrict__ Ws,
 constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3, kRingPred = 4;
 
 // a gathered tile: the staged 16 bytes of every thread (four per thread: rows idx / 32, 16-byte column idx % 32) into LDS
-template <bool SPLIT_IO>
-__device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[4], unsigned svalid, int tid, float& vmax) {
+template <bool SPLIT_IO, int MB>
+__device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[MB], unsigned svalid, int tid, float& vmax) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MB; ++i) {
         const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
         const bool ok = (svalid >> i) & 1u;
         if (SPLIT_IO) {                      // the row is a split image already: 16 bytes of it, as they are
@@ -294,13 +322,20 @@ __device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[4
     }
 }
 
-template <bool SPLIT_IO>
-__global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B, const float* __restrict__ in_base,
-                                                                const int* __restrict__ parent_block, long block_stride,
-                                                                const int* __restrict__ action,
-                                                                float* __restrict__ out_hidden, float* __restrict__ ppart,
-                                                                float* __restrict__ rpart) {
-    constexpr int ROWS = 64, TILE = ROWS * kLdW;
+// The job of workgroup (row block rb, job) -- the whole of ttt_ring_kernel, and one phase of a simulation in
+// ttt_run_kernel (whose pointers change meaning between two calls: no __restrict__ here).  Ends with every wave past
+// its last LDS access of the job but NOT with a barrier.
+// MB = 16-row blocks per workgroup: 4 (64 games x a group of cells, the shape for large batches) or 1 (16 games x ONE
+// cell: nine workgroups per 16 games, for batches that would leave most of the chip idle at 64 games a workgroup --
+// every workgroup still streams every weight fragment of its stages, so it is the shape of choice only while whole CUs
+// would otherwise have nothing to do).  `pslice`: which 128-float slice of a game's partials this job's sum goes to.
+template <bool SPLIT_IO, int MB = 4>
+__device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const float* in_base, const int* parent_block,
+                                              long block_stride, const int* action, float* out_hidden, float* ppart,
+                                              float* rpart, int rb, int job, int* trace_parent, int* trace_action,
+                                              bool coh = false) {
+    constexpr int ROWS = 16 * MB, TILE = ROWS * kLdW;
+    const int djob = MB == 4 ? job : 5 + job;        // descriptor list: the four cell groups, then the nine cells
     __shared__ __attribute__((aligned(16))) _Float16 sRing[3 * TILE];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
@@ -308,15 +343,15 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
                                                      // per action; [9*128..]: the cell's 128 reward-head weights;
                                                      // [10*128..]: the dense layer's bias
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
-    __shared__ float4 sAccP[4 * kThreadsW];          // prediction-conv partial, summed over the job's cells: slot [m][tid]
+    __shared__ float4 sAccP[MB * kThreadsW];          // prediction-conv partial, summed over the job's cells: slot [m][tid]
                                                      // belongs to thread tid alone (registers are the scarce resource)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (B + ROWS - 1) / ROWS;
-    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int job = bi & 3, rb = (bi >> 2) * 8 + xl;       // the four jobs of a row block share an XCD (its L2)
-    if (rb >= nrb) return;                           // grid padding (uniform per workgroup)
+    // the thread index through a copy the compiler cannot see through: inside ttt_run_kernel's simulation loop nothing
+    // derived from it can then be hoisted out of the loop and kept in registers across the other phases
+    int tid_opaque = threadIdx.x;
+    asm volatile("" : "+v"(tid_opaque));
+    const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
     const int row0 = rb * ROWS;
-    const int dbase = w.ring_first[job], d1 = w.ring_first[job + 1] - dbase;
+    const int dbase = w.ring_first[djob], d1 = w.ring_first[djob + 1] - dbase;
     const int n16 = lane & 15;
     const float4* wlane = reinterpret_cast<const float4*>(w.dyn_conv_s) + wave * 64 + lane;
 
@@ -332,45 +367,50 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
         long off = -1;
         int a = 0;
         if (b < B) {
-            const int pb = parent_block ? parent_block[b] : 0;
+            // coh: the selection was stored by another workgroup of this launch (ttt_run_kernel)
+            const int pb = !parent_block ? 0 : coh ? load1<true>(parent_block + b) : parent_block[b];
             if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-            a = action[b];
+            a = coh ? load1<true>(action + b) : action[b];
+            if (trace_parent != nullptr && job == 0) {      // this simulation's selection as the search made it
+                trace_parent[b] = pb;
+                trace_action[b] = a;
+            }
             if (a < 0 || a > 8) a = 0;
         }
         sRowOff[tid] = off;
         sAct[tid] = a;
     }
     __syncthreads();
-    const float* sptr[4];
+    const float* sptr[MB];
     unsigned svalid = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MB; ++i) {
         const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
         const long off = sRowOff[r];
         sptr[i] = in_base + (off >= 0 ? off : 0) + c4 * 4;
         if (off >= 0) svalid |= 1u << i;
     }
-    float4 stg[4];
+    float4 stg[MB];
     float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
-    ring_commit<SPLIT_IO>(sRing, stg, svalid, tid, vmax);
+    for (int i = 0; i < MB; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D0.w * 128);
+    ring_commit<SPLIT_IO, MB>(sRing, stg, svalid, tid, vmax);
     {   // stage 1's tile (a tap: every cell has at least four) is on its way while stage 0 starts
         const Desc D1 = desc[1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D1.w * 128);
+        for (int i = 0; i < MB; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + D1.w * 128);
     }
     __syncthreads();
 
     // rows with an output (game < B and a parent): one bit per row; this lane's rows are n16 + 16 m, m = 0..3
-    const unsigned long long rowmask = __ballot(sRowOff[lane] >= 0);
-    int lact[4];
+    const unsigned long long rowmask = __ballot(lane < ROWS && sRowOff[lane < ROWS ? lane : 0] >= 0);
+    int lact[MB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) lact[m] = sAct[16 * m + n16];
-    f32x4 acc[4], acx[4];
+    for (int m = 0; m < MB; ++m) lact[m] = sAct[16 * m + n16];
+    f32x4 acc[MB], acx[MB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) sAccP[m * kThreadsW + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 af[2][4][2];                              // activation fragments: ring over k-steps, carried across stages
+    for (int m = 0; m < MB; ++m) sAccP[m * kThreadsW + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 af[2][MB][2];                              // activation fragments: ring over k-steps, carried across stages
     int cur = 0, nxt = 1;                            // ring positions of this stage's and the next stage's tile
     Desc Dc = D0, Dn = desc[1], Dn2 = desc[2];
     MZ_TRACE_DECL;
@@ -419,7 +459,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
             const _Float16* np = sRing + nxt * TILE + n16 * kLdW + 8 * g;
             if (!primed) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MB; ++m) {
                     af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
                     af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
                 }
@@ -428,20 +468,20 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
             for (int s = 0; s < 4; ++s) {
                 if (s + 1 < 4) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    for (int m = 0; m < MB; ++m) {
                         af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
                         af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
                     }
                 } else if (commit) {                 // the next stage's first fragments (its tile is behind the barrier)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    for (int m = 0; m < MB; ++m) {
                         af[0][m][0] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW);
                         af[0][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
                     }
                 }
                 const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MB; ++m) {
                     const f16x8 ah = __builtin_bit_cast(f16x8, af[s & 1][m][0]), al = __builtin_bit_cast(f16x8, af[s & 1][m][1]);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[m], 0, 0, 0);
                     acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[m], 0, 0, 0);
@@ -450,16 +490,16 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
                 bw.v[2 * s] = wnext[(2 * s) * 512];  // in-place ring: the next stage's weight fragments
                 bw.v[2 * s + 1] = wnext[(2 * s + 1) * 512];
                 // pin the interleave: the next k-step's eight fragment reads, this k-step's twelve MFMAs, its VMEM reads
-                if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 if (s == 1 && commit) {              // the tile requested during the previous stage, then the barrier
-                    ring_commit<SPLIT_IO>(sRing + nxt * TILE, stg, svalid, tid, vmax);
+                    ring_commit<SPLIT_IO, MB>(sRing + nxt * TILE, stg, svalid, tid, vmax);
                     __syncthreads();
                 }
                 if (s == 2 && load2) {               // the tile two stages ahead
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src2);
+                    for (int i = 0; i < MB; ++i) stg[i] = *reinterpret_cast<const float4*>(sptr[i] + src2);
                 }
             }
         }
@@ -475,7 +515,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
             fold4(acc, acx);
             _Float16* sX = sRing + nxt * TILE;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 const float4 bq = *reinterpret_cast<const float4*>(sBias + lact[m] * 128 + lcol);
                 const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
                                     fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
@@ -495,9 +535,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
             {
                 const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol);
                 const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol);
-                float rdot[4];
+                float rdot[MB];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MB; ++m) {
                     const float v[4] = {fmaxf(acc[m][0] + bq.x, 0.f), fmaxf(acc[m][1] + bq.y, 0.f),
                                         fmaxf(acc[m][2] + bq.z, 0.f), fmaxf(acc[m][3] + bq.w, 0.f)};
                     // reward head (games/tictactoe.py:193-195): this lane's four columns
@@ -513,7 +553,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
                 }
                 // ... then the wave's sixteen columns: lanes n16 + 16 g, g = 0..3, hold the four parts of game n16
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MB; ++m) {
                     const unsigned x = __float_as_uint(rdot[m]);
                     const auto r16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
                     const unsigned y = __float_as_uint(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
@@ -526,7 +566,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
             MZ_TRACE_NW(4);
             if (SPLIT_IO) {                        // the tile is the row image the workspace wants: 16 bytes a thread
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MB; ++i) {
                     const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
                     if ((svalid >> i) & 1u)
                         __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(sH + r * kLdW + c4 * 8),
@@ -545,17 +585,17 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
         } else if (kind == kRingPred) {      // this cell's term of the prediction conv (games/tictactoe.py:201) joins sAccP
             fold4(acc, acx);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 const float4 q = sAccP[m * kThreadsW + tid];
                 acc[m] += f32x4{q.x, q.y, q.z, q.w};
             }
             if (has_next) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) sAccP[m * kThreadsW + tid] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                for (int m = 0; m < MB; ++m) sAccP[m * kThreadsW + tid] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
             } else {              // end of the job: one partial per (game, job)
-                float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;
+                float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;      // MB == 1: job = cell
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MB; ++m)
                     if ((rowmask >> (16 * m + n16)) & 1ull)
                         *reinterpret_cast<f32x4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) = acc[m];
             }
@@ -568,6 +608,41 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_ring_kernel(TttDev w, int B,
         Dn2 = Dn3;
     }
     note_range(vmax, w.range_flag);
+}
+
+// blockIdx -> (job, row block): the jobs of a row block (MB = 4: four cell groups x 64 games; MB = 1: nine cells x 16
+// games) run on one XCD (blockIdx % 8: workgroups are dealt to the XCDs round-robin) and share its L2 -- they gather the
+// same parent rows, and in ttt_run_kernel they hand their results to each other through it.  The cells of the 16-game
+// jobs go out heaviest first (centre, edges, corners: 11 / 8 / 6 stages).
+template <int MB = 4>
+__device__ __forceinline__ void ttt_job_of_block(int& job, int& rb) {
+    const int xl = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    if (MB == 4) {
+        job = bi & 3;
+        rb = (bi >> 2) * 8 + xl;
+    } else {
+        const int order = bi % 9;                    // 4 | 1 3 5 7 | 0 2 6 8
+        job = order == 0 ? 4 : order <= 4 ? 2 * order - 1 : order == 5 ? 0 : order == 6 ? 2 : order == 7 ? 6 : 8;
+        rb = (bi / 9) * 8 + xl;
+    }
+}
+// workgroups of the job kernel for a batch
+static int ttt_job_grid(int batch, int mb) {
+    const int nrb = (batch + 16 * mb - 1) / (16 * mb);
+    return 8 * (mb == 4 ? 4 : 9) * ((nrb + 7) / 8);
+}
+
+template <bool SPLIT_IO, int MB>
+__global__ __launch_bounds__(kThreadsW, MB == 4 ? 1 : 2) void ttt_ring_kernel(TttDev w, int B, const float* __restrict__ in_base,
+                                                                const int* __restrict__ parent_block, long block_stride,
+                                                                const int* __restrict__ action,
+                                                                float* __restrict__ out_hidden, float* __restrict__ ppart,
+                                                                float* __restrict__ rpart) {
+    int job, rb;
+    ttt_job_of_block<MB>(job, rb);
+    if (rb >= (B + 16 * MB - 1) / (16 * MB)) return;  // grid padding (uniform per workgroup)
+    ttt_ring_body<SPLIT_IO, MB>(w, B, in_base, parent_block, block_stride, action, out_hidden, ppart, rpart, rb, job, nullptr,
+                                nullptr);
 }
 
 // One 128 x 128 GEMM stage on split operands without the job kernel's pipelining: acc += sA[32][128] * W, weights in b
@@ -720,35 +795,64 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
 // with the weights as the row operand: a lane then holds four consecutive columns of one game, split and stored 8 bytes
 // at a time.  The ten head outputs are one more 16-column block (wave 0).
 // Results: sOut[game][0..8] logits, [9] value, [10] reward.  Ends with a barrier.
-template <int NP, bool REWARD>
+// The head's weights as a lane holds them: what ttt_head16 needs that does not depend on any game (ttt_run_kernel asks for
+// them while it waits for the row block's partials).
+struct HeadW {
+    float4 db[2];                  // Dense bias of this lane's columns
+    float hb;                      // head bias of output lane % 16
+    float4 bF[2][4][2];            // Dense fragments [column block][k-step][h | l]
+    float4 hF[4][2];               // head fragments (wavefront 0)
+};
+__device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW& hw) {
+    int tid_opaque = threadIdx.x;                    // (opaque to the compiler: see ttt_ring_body)
+    asm volatile("" : "+v"(tid_opaque));
+    const int tid = tid_opaque & (kThreads - 1), lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4;
+    // biases first: a load issued after the MFMAs would show its whole latency
+    hw.db[0] = *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 4 * g);
+    hw.db[1] = *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 16 + 4 * g);
+    hw.hb = w.pred_head_b[n16];
+    const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + wave * 128 + lane;   // column block 2 wave + c
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            hw.bF[c][s][0] = wp[(2 * s) * 512 + c * 64];
+            hw.bF[c][s][1] = wp[(2 * s + 1) * 512 + c * 64];
+        }
+    if (wave == 0) {
+        const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + lane;                 // column block 0
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            hw.hF[s][0] = hp[(2 * s) * 512];
+            hw.hF[s][1] = hp[(2 * s + 1) * 512];
+        }
+    }
+}
+
+template <int NP, bool REWARD, bool COH = false>
 __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, const float* __restrict__ ppart,
-                                           const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12]) {
+                                           const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12],
+                                           const HeadW& hw) {
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
     float vmax = 0.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // in a 512-thread workgroup (ttt_run_kernel) the upper four wavefronts repeat the work of the lower four: the same
+    // values into the same LDS words; every barrier below is then reached by the whole workgroup
+    int tid_opaque = threadIdx.x;                    // (opaque to the compiler: see ttt_ring_body)
+    asm volatile("" : "+v"(tid_opaque));
+    const int tid = tid_opaque & (kThreads - 1), lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g = lane >> 4;
-    // biases first: a load issued after the MFMAs would show its whole latency
-    const float4 db[2] = {*reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 4 * g),
-                          *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 16 + 4 * g)};
-    const float hb = w.pred_head_b[n16];
+    const float4 (&db)[2] = hw.db;
+    const float hb = hw.hb;
+    const float4 (&bF)[2][4][2] = hw.bF;
+    const float4 (&hF)[4][2] = hw.hF;
     // the reward partials too (wave 1): requested now, summed under the first barrier instead of at the very end
     float rp[9];
     if (REWARD && wave == 1 && lane < 16) {
         const int b = min(row0 + lane, B - 1);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) rp[c] = rpart[(size_t)b * 9 + c];
-    }
-    float4 bF[2][4][2], hF[4][2];                    // [column block][k-step][h | l]
-    {
-        const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + wave * 128 + lane;   // column block 2 wave + c
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                bF[c][s][0] = wp[(2 * s) * 512 + c * 64];
-                bF[c][s][1] = wp[(2 * s + 1) * 512 + c * 64];
-            }
+        for (int c = 0; c < 9; ++c) rp[c] = load1<COH>(rpart + (size_t)b * 9 + c);
     }
     {   // every load of the tile is issued before the first use
         const int c4 = tid & 31;
@@ -759,15 +863,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             const int b = min(row0 + (tid >> 5) + 8 * i, B - 1);
             const float4* pp = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
 #pragma unroll
-            for (int c = 0; c < NP; ++c) v[i][c] = pp[c * 32];
-        }
-        if (wave == 0) {
-            const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + lane;                 // column block 0
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                hF[s][0] = hp[(2 * s) * 512];
-                hF[s][1] = hp[(2 * s + 1) * 512];
-            }
+            for (int c = 0; c < NP; ++c) v[i][c] = load4<COH>(pp + c * 32);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -867,7 +963,9 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
     const int row0 = blockIdx.x * 16;
-    ttt_head16<NP, !INITIAL>(w, B, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
+    HeadW hw;
+    ttt_head_weights(w, hw);
+    ttt_head16<NP, !INITIAL>(w, B, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
     const int tid = threadIdx.x;
     if (tid < 16) {
         const int b = row0 + tid;
@@ -886,7 +984,7 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
 // logits / value / reward, which go from the head to the tree code through LDS.  One launch boundary less per
 // simulation.  Tree side: 16 lanes per game (A = 9), exactly step_kernel<16, true>'s code (mz_tree_dev.h), so the trees
 // are bit-identical to the separate launches.
-template <bool SELECT>
+template <bool SELECT, int NP>
 __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolDev p, int nb, const float* __restrict__ ppart,
                                                                  const float* __restrict__ rpart, float* __restrict__ out_reward,
                                                                  float* __restrict__ out_value, float* __restrict__ out_logits,
@@ -896,13 +994,17 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     __shared__ float sOut[16][12];
     // the 16 games of a block lie in the row block the job kernel ran on this block's XCD (blockIdx % 8): their partials
     // are in this XCD's L2
+    // (NP = 9, the 16-game jobs: row block b of the job kernel ran on XCD b % 8, and so does block b here)
     const int xk = blockIdx.x >> 3;
-    const int tid = threadIdx.x, row0 = (((xk >> 2) * 8 + (blockIdx.x & 7)) * 4 + (xk & 3)) * 16;
+    const int tid = threadIdx.x,
+              row0 = NP == 9 ? blockIdx.x * 16 : (((xk >> 2) * 8 + (blockIdx.x & 7)) * 4 + (xk & 3)) * 16;
     const int tree = row0 + tid / G, gl = tid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
     MZ_TRACE_DECL;
-    ttt_head16<4, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut);
+    HeadW hw;
+    ttt_head_weights(w, hw);
+    ttt_head16<NP, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
     MZ_TRACE(0);                                                              // head
     if (active && gl < 11) {                                         // the plain outputs of mz_infer_recurrent
         const float x = sOut[tid / G][gl];
@@ -918,6 +1020,184 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         select_tree<G>(p, tree, active, gl, out_parent, out_action);
+    }
+}
+
+// ---- run_mcts of a TicTacToe batch in ONE launch (ttt_run_kernel) ---------------------------------------------------
+// The four workgroups of a row block (64 games x four cell groups) stay resident for all N simulations of a move and
+// meet twice per simulation: after the jobs (the prediction-conv partials, reward partials and hidden' rows of the row
+// block are complete -> each workgroup runs the head and the tree step of 16 of the 64 games) and after the tree steps
+// (the next selection of all 64 games is known -> the next jobs gather their parent rows).  What a launch boundary did
+// for these two hand-overs -- make one workgroup's stores visible to the others -- the XCD's L2 does: the four
+// workgroups run on ONE XCD (ttt_job_of_block), a store is in that L2 once `s_waitcnt vmcnt(0)` has returned, and a
+// reader only has to drop its CU's L1 (`buffer_inv sc1`) after it has seen the arrival counter.  The expensive half of
+// an agent-scope release (`buffer_wbl2`: write the whole L2 back) is never needed on that path.
+//   * Where the workgroups run is checked, not assumed: each ORs the bit of its hardware XCC id into a word of its row
+//     block before a first meeting made of agent-scope atomics only; four equal ids -> the L2 path; anything else -> the
+//     same protocol with full agent-scope release / acquire fences around every meeting (correct wherever the workgroups
+//     are, slower).
+//   * No wave can wait for ever: the workgroups of a launch are dispatched in blockIdx order XCD by XCD, a row block's
+//     four are consecutive in their XCD's order, so whenever a workgroup is resident every workgroup it can ever wait for
+//     is resident too or will be as soon as some complete row block ahead of it retires; and a meeting that is not
+//     complete after kRunSpinTicks of the 100 MHz wall clock gives up, raises bit 3 of the pool's error flag and ends
+//     the workgroup's run (every later meeting of the others then times out the same way).
+// The arrival counters are 64-bit words that carry the launch's serial number in their upper bits (host: mz_net::run_epoch),
+// set by an atomic max at the first meeting: nothing has to be cleared between launches, and a launch that gave up leaves
+// nothing behind that the next one could take for its own arrivals.
+constexpr int kRunEpochShift = 20;
+constexpr long long kRunSpinTicks = 100000000;       // 1 s of s_memrealtime
+
+constexpr int kRunMaxRowBlocks = 4096;               // 262144 games per launch
+struct RunSync {
+    unsigned long long* arrive;     // [row block]: (epoch << 20) + arrivals of this launch
+    unsigned* xcc_mask;             // [row block]: bits of the XCC ids its workgroups have run on
+    unsigned* stats;                // [0] row-block runs that took the fence path, [1] row-block runs
+    unsigned long long epoch_base;  // epoch << kRunEpochShift of this launch
+    int force_fences;               // tests: take the agent-scope fence path whatever the placement
+};
+
+// A meeting of the four workgroups of a row block, in two halves so that loads which do not depend on the others can be
+// requested in between.  All 512 threads call both.  `fenced`: full agent-scope release / acquire (workgroups on
+// different XCDs).  meet_arrive: this workgroup's stores are visible, its arrival counted; the workgroup that arrives
+// last learns so from the counter's old value and does not have to look again.  meet_wait -> false: gave up.
+__device__ __forceinline__ void meet_arrive(unsigned long long* arrive, unsigned long long target, bool fenced, bool first,
+                                            unsigned long long epoch_base, int* s_flag) {
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // buffer_wbl2 sc1 + wait
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // this wave's stores are in the XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (first) {
+            const unsigned long long was = __hip_atomic_fetch_max(arrive, epoch_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(was));                                   // performed before the arrival below is issued
+        }
+        const unsigned long long before = __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag[0] = (long long)(before + 1 - target) >= 0 ? 1 : 0;         // 1: everybody is here already
+    }
+}
+__device__ __forceinline__ bool meet_wait(unsigned long long* arrive, unsigned long long target, bool fenced, int* s_flag,
+                                          int* err_flag) {
+    if (threadIdx.x == 0 && s_flag[0] == 0) {
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        for (;;) {
+            const unsigned long long seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((long long)(seen - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > kRunSpinTicks) {
+                ok = 0;
+                atomicOr(err_flag, 8);
+                break;
+            }
+        }
+        s_flag[0] = ok;
+    }
+    __syncthreads();
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // buffer_inv sc1
+    return s_flag[0] != 0;                  // (the caller alternates between two flag words from meeting to meeting)
+}
+
+// Experiment builds (-DMZ_RUN_TRACE, tools/ttt_run_trace.py): thread 0 of every workgroup adds the 100 MHz wall-clock
+// ticks of each phase of a simulation to g_run_trace[blockIdx][phase].  Compiles to nothing in the library.
+#ifdef MZ_RUN_TRACE
+__device__ unsigned long long g_run_trace[2048][8];
+#define MZ_RUN_STAMP(phase)                                                       \
+    do {                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {                              \
+            const long long now_ = wall_clock64();                                \
+            g_run_trace[blockIdx.x][phase] += (unsigned long long)(now_ - rt_t_); \
+            rt_t_ = now_;                                                         \
+        }                                                                         \
+    } while (0)
+#define MZ_RUN_STAMP_DECL long long rt_t_ = wall_clock64()
+#else
+#define MZ_RUN_STAMP(phase)
+#define MZ_RUN_STAMP_DECL
+#endif
+
+template <bool SPLIT_IO>
+__global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev p, RunSync sync, int nb0, int nsim,
+                                                               int final_select, float* hidden_base, int* parent_block,
+                                                               long block_stride, int* action, float* ppart, float* rpart,
+                                                               float* out_reward, float* out_value, float* out_logits,
+                                                               long out_stride, int* trace_parent, int* trace_action) {
+    constexpr int G = 16;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
+    __shared__ float sOut[16][12];
+    __shared__ int s_flags[3];                       // [0], [1]: the meetings' flag words, alternating; [2]: fence path
+    int job, rb;
+    ttt_job_of_block<4>(job, rb);
+    if (rb >= (p.T + 63) / 64) return;               // grid padding: the same for the four workgroups of a row block
+    // ---- first meeting: agent-scope atomics only (no data crosses it); tells where the four workgroups run
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;        // hwreg(HW_REG_XCC_ID, 0, 4)
+        const unsigned was = __hip_atomic_fetch_or(sync.xcc_mask + rb, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(was) : "memory");
+    }
+    unsigned long long target = sync.epoch_base + 4;
+    meet_arrive(sync.arrive + rb, target, false, true, sync.epoch_base, s_flags);
+    bool alive = meet_wait(sync.arrive + rb, target, true, s_flags, p.err_flag);
+    if (threadIdx.x == 0) {
+        const unsigned m = __hip_atomic_load(sync.xcc_mask + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flags[2] = (sync.force_fences != 0 || __builtin_popcount(m) != 1) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool fenced = s_flags[2] != 0;
+    if (threadIdx.x == 0 && job == 0) {
+        atomicAdd(sync.stats + 1, 1u);
+        if (fenced) atomicAdd(sync.stats, 1u);
+    }
+    const int hrow0 = rb * 64 + job * 16;
+    MZ_RUN_STAMP_DECL;
+#pragma unroll 1
+    for (int i = 0; i < nsim && alive; ++i) {
+        asm volatile("" ::: "memory");
+        const int nb = nb0 + i;
+        const bool traced = trace_parent != nullptr;
+        ttt_ring_body<SPLIT_IO>(w, p.T, hidden_base, parent_block, block_stride, action,
+                                hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
+                                traced ? trace_parent + (size_t)i * p.T : nullptr,
+                                traced ? trace_action + (size_t)i * p.T : nullptr, true);
+        MZ_RUN_STAMP(0);
+        target += 4;
+        meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags + 1);
+        HeadW hw;                                    // requested while the arrival is on its way
+        ttt_head_weights(w, hw);
+        alive = meet_wait(sync.arrive + rb, target, fenced, s_flags + 1, p.err_flag);
+        MZ_RUN_STAMP(1);
+        if (!alive) break;
+        // ---- head and tree step of 16 games (ttt_head_step_kernel's body): 16 of the row block's 64 games, by the
+        // workgroup's lower four wavefronts (lane geometry from an opaque copy of the thread index: not hoisted)
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int ht = tx & (kThreads - 1);
+        const int tree = tx < kThreads ? hrow0 + ht / G : p.T, gl = ht % G;
+        const bool active = tree < p.T && p.n_root[tree] > 0;
+        const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
+        ttt_head16<4, true, true>(w, p.T, hrow0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
+        const bool store_out = out_stride != 0 || i + 1 == nsim;                  // nobody overwrites these
+        if (active && gl < 11 && store_out) {
+            const float x = sOut[ht / G][gl];
+            if (gl < 9) out_logits[((size_t)i * out_stride + tree) * 9 + gl] = x;
+            else if (gl == 9) out_value[(size_t)i * out_stride + tree] = x;
+            else out_reward[(size_t)i * out_stride + tree] = x;
+        }
+        MZ_RUN_STAMP(2);
+        const float* mine = sOut[ht / G];
+        backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9], pf);
+        if (i + 1 < nsim || final_select != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            MZ_RUN_STAMP(3);
+            select_tree<G>(p, tree, active, gl, parent_block, action);
+            MZ_RUN_STAMP(4);
+            if (i + 1 < nsim) {                      // the selection of all 64 games, for the next jobs
+                target += 4;
+                meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags);
+                alive = meet_wait(sync.arrive + rb, target, fenced, s_flags, p.err_flag);
+                MZ_RUN_STAMP(5);
+            }
+        }
     }
 }
 
@@ -2556,6 +2836,13 @@ struct mz_net {
     int scratch_cap = 0;
     int* range_flag = nullptr;     // device word raised by the kernels when a value leaves the split-f16 domain
     float* static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array (mz_infer_recurrent_noalloc)
+    // ttt_run_kernel's meeting words, zeroed once: [kRunMaxRowBlocks] arrival counters, then XCC masks, then two
+    // counters (row-block runs that took the fence path, row-block runs in all)
+    unsigned long long* run_sync = nullptr;
+    unsigned long long run_epoch = 0; // serial number of the last ttt_run_kernel launch
+    int job_rows = 0;                 // mz_debug_set_job_rows: 0 = by batch size (ttt_mb), 16 or 64 = that shape always
+    int run_mode = 0;                 // mz_debug_set_run_mode: 0 = one launch where possible, 1 = ... with agent-scope
+                                      // fences at every meeting, 2 = a launch per simulation
     bool hidden_split = false;        // inside a native move: the hidden workspace holds split images (mz_net_begin_move)
     hipEvent_t mid_event = nullptr;   // measurement hook, see mz_net_set_mid_event
 };
@@ -2723,6 +3010,22 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             }
         }
         t.ring_first[4] = (int)desc.size() / 4;
+        for (int c = 0; c < 9; ++c) {                 // the nine single-cell jobs of the 16-game workgroups
+            t.ring_first[5 + c] = (int)desc.size() / 4;
+            int valid[9], nv = 0;
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
+                if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) valid[nv++] = tp;
+            }
+            for (int i = 0; i < nv; ++i) {
+                const int tp = valid[i];
+                push(i == 0 ? kRingTapFirst : i == nv - 1 ? kRingTapLast : kRingTap, c, tp,
+                     (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
+            }
+            push(kRingDense, c, 9, 0);
+            push(kRingPred, c, 10 + c, 0);
+        }
+        t.ring_first[14] = (int)desc.size() / 4;
         put(reinterpret_cast<const float*&>(t.ring_desc), pk.add(desc));
         put(t.pred_head_p, pk.add_split16(headW.data(), 16, 16));
         put(t.pred_head_b, pk.add(headB));
@@ -2901,6 +3204,17 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         delete net;
         return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
+    if (kind == MZ_NET_TICTACTOE) {
+        const size_t bytes = (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned)) + 2 * sizeof(unsigned);
+        e = hipMalloc(reinterpret_cast<void**>(&net->run_sync), bytes);
+        if (e == hipSuccess) e = hipMemset(net->run_sync, 0, bytes);
+        if (e != hipSuccess) {
+            if (net->run_sync) (void)hipFree(net->run_sync);
+            (void)hipFree(net->weights);
+            delete net;
+            return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "allocation failed: %s", hipGetErrorString(e));
+        }
+    }
     for (auto& f : fix) *f.first = net->weights + f.second;
     net->range_flag = reinterpret_cast<int*>(net->weights + range_off);
     net->ttt.range_flag = net->cart.range_flag = net->atari.range_flag = net->range_flag;
@@ -2915,6 +3229,7 @@ int mz_net_destroy(mz_net_t* net) {
     if (net->weights) (void)hipFree(net->weights);
     if (net->ppart) (void)hipFree(net->ppart);
     if (net->rpart) (void)hipFree(net->rpart);
+    if (net->run_sync) (void)hipFree(net->run_sync);
     delete net;
     return MZ_OK;
 }
@@ -2943,6 +3258,18 @@ int mz_net_status(mz_net_t* net, int32_t* out_flags_host) {
     *out_flags_host = flags;
     return MZ_OK;
 }
+
+#ifdef MZ_RUN_TRACE
+int mz_debug_run_trace(uint64_t* out, int64_t out_bytes) {
+    MZ_REQUIRE(out != nullptr && out_bytes == (int64_t)sizeof(g_run_trace), "out must hold %zu bytes", sizeof(g_run_trace));
+    void* sym = nullptr;
+    MZ_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_run_trace)));
+    MZ_HIP(hipDeviceSynchronize());
+    MZ_HIP(hipMemcpy(out, sym, (size_t)out_bytes, hipMemcpyDeviceToHost));
+    MZ_HIP(hipMemset(sym, 0, (size_t)out_bytes));
+    return MZ_OK;
+}
+#endif
 
 #ifdef MZ_TREE_TRACE
 // experiment builds only: the per-wavefront phase counters of THIS translation unit (the job kernel's stamps)
@@ -3016,16 +3343,32 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
 }
 
 // The TicTacToe job kernel, reading and writing f32 hidden rows or, inside a native move, their split images.
+// Batches up to this many games run as 16-game single-cell jobs (nine workgroups per 16 games) and a head that sums nine
+// partials; larger ones as 64-game jobs over four cell groups.  Where 64-game jobs would occupy fewer than half of the
+// CUs the smaller jobs win although every workgroup streams its stages' weights again (measured: DESIGN.md section 3).
+constexpr int kTttSmallBatch = 1792;
+static int ttt_mb(const mz_net* net, int batch) {
+    return net->job_rows == 16 ? 1 : net->job_rows == 64 ? 4 : batch <= kTttSmallBatch ? 1 : 4;
+}
+
 static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, const int* parent_block, long bs,
                               const int* action, float* out_hidden, bool split_hidden, float* ppart, float* rpart) {
     hipStream_t st = net->stream;
-    const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
-    if (split_hidden)
-        ttt_ring_kernel<true><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                          out_hidden, ppart, rpart);
-    else
-        ttt_ring_kernel<false><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
-                                                           out_hidden, ppart, rpart);
+    const int mb = ttt_mb(net, batch), grid = ttt_job_grid(batch, mb);
+    if (mb == 1) {
+        if (split_hidden)
+            ttt_ring_kernel<true, 1><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                 out_hidden, ppart, rpart);
+        else
+            ttt_ring_kernel<false, 1><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                  out_hidden, ppart, rpart);
+    } else if (split_hidden) {
+        ttt_ring_kernel<true, 4><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                             out_hidden, ppart, rpart);
+    } else {
+        ttt_ring_kernel<false, 4><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                              out_hidden, ppart, rpart);
+    }
 }
 
 // split_hidden: the hidden rows read and written are the split images of a native move's workspace (TicTacToe)
@@ -3055,8 +3398,12 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
         launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden, ppart, rpart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
-        ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
-                                                           out_reward, out_value, out_logits, out_value_raw);
+        if (ttt_mb(net, batch) == 1)
+            ttt_head_kernel<false, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
+                                                               out_reward, out_value, out_logits, out_value_raw);
+        else
+            ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
+                                                               out_reward, out_value, out_logits, out_value_raw);
     } else if (net->kind == MZ_NET_ATARI_SHAPED) {
         atari_kernel<false><<<(batch + 63) / 64, kThreadsW, 0, st>>>(net->atari, batch, hidden_base, parent_block, bs, action,
                                                                     out_hidden, out_reward, out_value, out_logits,
@@ -3127,8 +3474,44 @@ static bool run_fusable_cart(const mz_net* net, const mz_pool* pool) {
 static bool run_fusable_atari(const mz_net* net, const mz_pool* pool) {
     return net->kind == MZ_NET_ATARI_SHAPED && pool->dev.A == 18 && pool->dev.N + 2 <= kLogLds;
 }
+static bool run_fusable_ttt(const mz_net* net, const mz_pool* pool) {
+    // the fused head + tree step is built for 16 lanes per tree; a row block's four workgroups must be co-resident, which
+    // one 512-thread workgroup per CU always allows
+    return net->kind == MZ_NET_TICTACTOE && net->run_mode != 2 && pool->G == 16 && pool->dev.A == 9 &&
+           ttt_mb(net, pool->dev.T) == 4 &&
+           (pool->dev.T + 63) / 64 <= kRunMaxRowBlocks;
+}
 __attribute__((visibility("hidden"))) int mz_net_run_is_one_launch(const mz_net* net, const mz_pool* pool) {
-    return run_fusable_cart(net, pool) || run_fusable_atari(net, pool) ? 1 : 0;
+    return run_fusable_cart(net, pool) || run_fusable_atari(net, pool) || run_fusable_ttt(net, pool) ? 1 : 0;
+}
+
+int mz_debug_set_run_mode(mz_net_t* net, int32_t mode) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    MZ_REQUIRE(mode >= 0 && mode <= 2, "run mode must be 0, 1 or 2 (got %d)", mode);
+    net->run_mode = mode;
+    return MZ_OK;
+}
+
+int mz_debug_set_job_rows(mz_net_t* net, int32_t rows) {
+    MZ_REQUIRE(net != nullptr, "net is NULL");
+    MZ_REQUIRE(rows == 0 || rows == 16 || rows == 64, "job rows must be 0, 16 or 64 (got %d)", rows);
+    net->job_rows = rows;
+    return MZ_OK;
+}
+
+int mz_debug_run_info(mz_net_t* net, int64_t* out2_host) {
+    MZ_REQUIRE(net != nullptr && out2_host != nullptr, "net/out2_host is NULL");
+    out2_host[0] = out2_host[1] = 0;
+    if (!net->run_sync) return MZ_OK;
+    MZ_HIP(hipSetDevice(net->device));
+    MZ_HIP(hipStreamSynchronize(net->stream));
+    unsigned host[2] = {0, 0};
+    const char* base = reinterpret_cast<const char*>(net->run_sync) +
+                       (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned));
+    MZ_HIP(hipMemcpy(host, base, sizeof(host), hipMemcpyDeviceToHost));
+    out2_host[0] = host[0];
+    out2_host[1] = host[1];
+    return MZ_OK;
 }
 
 int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
@@ -3156,6 +3539,35 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         cartpole16_run_kernel<<<(T + 15) / 16, kRunThreads, dyn_lds, net->stream>>>(
             net->cart, pool->dev, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
             out_reward, out_value, out_logits, (long)out_stride, trace_parent, trace_action);
+        s = launch_status("recurrent inference + tree step, all simulations");
+        if (s != MZ_OK) return s;
+        mz_pool_commit_run(pool, num_simulations, final_select != 0);
+        return MZ_OK;
+    }
+    if (run_fusable_ttt(net, pool)) {
+        int nb0 = 0;
+        int s = mz_pool_begin_run(pool, num_simulations, final_select != 0, &nb0);
+        if (s != MZ_OK) return s;
+        MZ_HIP(hipSetDevice(net->device));
+        s = ensure_scratch(net, T);
+        if (s != MZ_OK) return s;
+        RunSync sync;
+        sync.arrive = net->run_sync;
+        sync.xcc_mask = reinterpret_cast<unsigned*>(net->run_sync + kRunMaxRowBlocks);
+        sync.stats = sync.xcc_mask + kRunMaxRowBlocks;
+        sync.epoch_base = (++net->run_epoch) << kRunEpochShift;
+        sync.force_fences = net->run_mode == 1;
+        const int grid = 32 * (((T + 63) / 64 + 7) / 8);
+        if (net->hidden_split)
+            ttt_run_kernel<true><<<grid, kThreadsW, 0, net->stream>>>(
+                net->ttt, pool->dev, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
+                action, net->ppart, net->rpart, out_reward, out_value, out_logits, (long)out_stride, trace_parent,
+                trace_action);
+        else
+            ttt_run_kernel<false><<<grid, kThreadsW, 0, net->stream>>>(
+                net->ttt, pool->dev, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
+                action, net->ppart, net->rpart, out_reward, out_value, out_logits, (long)out_stride, trace_parent,
+                trace_action);
         s = launch_status("recurrent inference + tree step, all simulations");
         if (s != MZ_OK) return s;
         mz_pool_commit_run(pool, num_simulations, final_select != 0);
@@ -3263,13 +3675,23 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
                       net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-    const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
-    if (with_select)
-        ttt_head_step_kernel<true><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart, out_reward,
-                                                              out_value, out_logits, parent_block, action);
-    else
-        ttt_head_step_kernel<false><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart, out_reward,
-                                                               out_value, out_logits, parent_block, action);
+    if (ttt_mb(net, batch) == 1) {
+        const int grid = (batch + 15) / 16;
+        if (with_select)
+            ttt_head_step_kernel<true, 9><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+                                                                     out_reward, out_value, out_logits, parent_block, action);
+        else
+            ttt_head_step_kernel<false, 9><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+                                                                      out_reward, out_value, out_logits, parent_block, action);
+    } else {
+        const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
+        if (with_select)
+            ttt_head_step_kernel<true, 4><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+                                                                     out_reward, out_value, out_logits, parent_block, action);
+        else
+            ttt_head_step_kernel<false, 4><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+                                                                      out_reward, out_value, out_logits, parent_block, action);
+    }
     s = launch_status("recurrent inference + tree step");
     if (s != MZ_OK) return s;
     mz_pool_commit_backprop(pool, with_select != 0);

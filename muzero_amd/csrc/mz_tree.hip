@@ -844,6 +844,9 @@ int mz_pool_counters(mz_pool_t* pool, int64_t* out4_host) {
     int err = 0;
     MZ_HIP(hipMemcpyAsync(&err, pool->dev.err_flag, sizeof(int), hipMemcpyDeviceToHost, pool->stream));
     MZ_HIP(hipStreamSynchronize(pool->stream));
+    if (err & 8)
+        return mz::fail(MZ_ERR_HIP, "a one-launch run of simulations gave up waiting for the workgroups of its row block "
+                                    "(flags 0x%x): results of that move are invalid", err);
     if (err != 0) return mz::fail(MZ_ERR_INVALID_ARG, "device-side validation failed (flags 0x%x): bad legal/n_legal", err);
     out4_host[0] = host[0];
     out4_host[1] = host[1];

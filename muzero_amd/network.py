@@ -261,6 +261,22 @@ class Network:
         _lib.check(self._lib.mz_net_status(self._h, ctypes.addressof(flags)))
         return int(flags.value)
 
+    def set_run_mode(self, mode: int) -> None:
+        """mz_debug_set_run_mode (tests, measurement): how mz_infer_recurrent_run / mz_search_move run a TicTacToe move's
+        simulations -- 0 one launch (default), 1 one launch with agent-scope fences at every meeting, 2 a launch per
+        simulation.  Same results in every mode."""
+        _lib.check(self._lib.mz_debug_set_run_mode(self._h, int(mode)))
+
+    def set_job_rows(self, rows: int) -> None:
+        """mz_debug_set_job_rows (tests, measurement): the TicTacToe job kernel's games per workgroup, 0 = by batch size."""
+        _lib.check(self._lib.mz_debug_set_job_rows(self._h, int(rows)))
+
+    def run_info(self):
+        """mz_debug_run_info -> (row-block runs that took the fence path, row-block runs); synchronises."""
+        out = np.zeros(2, np.int64)
+        _lib.check(self._lib.mz_debug_run_info(self._h, out.ctypes.data))
+        return int(out[0]), int(out[1])
+
     def check_range(self) -> None:
         """Raises MuZeroError if an inference since the last check saturated an activation (see include/mzhip.h,
         mz_net_create: the numeric domain of the split-f16 kernels)."""

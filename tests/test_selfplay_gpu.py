@@ -679,3 +679,63 @@ def test_integration_section_1_verbatim_with_the_hip_network():
         state, reward, done, _ = env.step(int(history.actions[m]))
         assert reward == history.rewards[m]
     assert done
+
+
+@pytest.mark.parametrize('T', [64, 300, 1100])
+def test_tictactoe_one_launch_move_equals_the_launch_per_simulation(T):
+    """ttt_run_kernel (all simulations of a move in one launch; a row block's four workgroups meet through their XCD's L2)
+    against the launch-per-simulation kernels it replaces, and against itself with agent-scope fences at every meeting
+    (the path it takes when the workgroups are not on one XCD): results, traces and hidden workspace bit for bit.
+    Ragged legal lists, finished games, a batch that is not a multiple of 64."""
+    import torch
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    N, A = 25, 9
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=11)
+    net.set_job_rows(64)          # the one-launch move is the 64-game jobs' (by default only batches > 1792 take them)
+    rng = np.random.default_rng(T)
+    obs = rng.integers(0, 2, size=(T, 27)).astype(np.float32)
+    n_legal = rng.integers(0, A + 1, size=T).astype(np.int32)
+    n_legal[:4] = A
+    legal = np.zeros((T, A), np.int32)
+    noise = np.zeros((T, A))
+    for t in range(T):
+        legal[t, :n_legal[t]] = np.sort(rng.permutation(A)[:n_legal[t]])
+        if n_legal[t]:
+            noise[t, :n_legal[t]] = rng.dirichlet([1.0] * int(n_legal[t]))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = (dev(obs), dev(noise), dev(rng.random(T)), dev(np.ones(T)), dev(legal), dev(n_legal))
+    results = {}
+    modes = (2, 0, 1)
+    for mode in modes:
+        net.set_run_mode(mode)
+        fenced0, runs0 = net.run_info()
+        search = LockstepSearch(config, net, num_trees=T)
+        search.hidden.zero_()
+        tr = {}
+        out = [x.cpu().numpy().copy() for x in search.run_native(*args, trace=tr)]
+        search.pool.counters()                                    # raises if the run gave up or the pool is inconsistent
+        fenced1, runs1 = net.run_info()
+        row_blocks = (T + 63) // 64
+        assert runs1 - runs0 == (0 if mode == 2 else row_blocks)
+        if mode == 1:
+            assert fenced1 - fenced0 == row_blocks
+        results[mode] = (out, {k: v.cpu().numpy().copy() for k, v in tr.items()}, search.hidden.cpu().numpy().copy(),
+                         [search.pool.read_block(int(t), e) for t in np.nonzero(n_legal > 0)[0][[0, -1]] for e in (0, 1, N)])
+        if mode == 0:
+            results['fenced_in_default_mode'] = fenced1 - fenced0
+    net.set_run_mode(0)
+    live = n_legal > 0
+    for mode in modes[1:]:
+        for a, b in zip(results[mode][0], results[2][0]):
+            np.testing.assert_array_equal(a, b)
+        for k in results[2][1]:
+            np.testing.assert_array_equal(results[mode][1][k], results[2][1][k], err_msg=f'trace {k}, mode {mode}')
+        np.testing.assert_array_equal(results[mode][2][:, live].view(np.uint32), results[2][2][:, live].view(np.uint32))
+        for x, y in zip(results[mode][3], results[2][3]):
+            for key in x:
+                np.testing.assert_array_equal(x[key], y[key])
+    assert results[2][0][0][live].sum() == live.sum() * N
+    # on this part the four workgroups of a row block are dealt to one XCD: the L2 path is the one that ran
+    assert results['fenced_in_default_mode'] == 0
