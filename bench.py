@@ -71,10 +71,10 @@ class SyntheticTreeMove:
     trees of a GPU are split into `lanes` pools stepped on separate HIP streams (trees are independent): a step of one
     pool ends with its deepest tree, and the other pools' launches fill the chip meanwhile.  Every pool's move is
     enqueued by one native call (mz_search_move_injected)."""
-    dominant = 'step_kernel'
+    dominant = 'run_injected_kernel'
     bound = 'hbm'
 
-    def __init__(self, wl, device, seed, lanes=1, event_stride=5):
+    def __init__(self, wl, device, seed, lanes=1, event_stride=5, lanes_per_tree=0):
         from muzero_amd.tree_pool import TreePool
         self.event_stride = event_stride
         assert wl['T'] % lanes == 0, 'lanes must divide the trees per GPU'
@@ -90,7 +90,7 @@ class SyntheticTreeMove:
             with torch.cuda.stream(stream):
                 pool = TreePool(num_trees=Tl, num_actions=wl['A'], max_simulations=wl['N'], num_players=wl['players'],
                                 discount=wl['discount'], default_value=wl['default'], known_bounds=wl['bounds'],
-                                device=device)
+                                device=device, lanes_per_tree=lanes_per_tree)
             self.lanes.append(dict(pool=pool, stream=stream, logits=self.logits[:, sl].contiguous(),
                                    values=self.values[:, sl].contiguous(), rewards=self.rewards[:, sl].contiguous(),
                                    noise=self.noise[sl].contiguous(), u=self.u[sl].contiguous(),
@@ -146,12 +146,11 @@ class SyntheticTreeMove:
         return float(np.mean(ms)) * 1e-3 if ms else None
 
     def run_durations(self):
-        """mean time (s) per fused step inside an un-evented run of N-1 of them (launch gaps included: an upper bound
-        of the kernel's duration)"""
+        """mean duration (s) of the ONE launch that holds a move's N simulations (run_injected_kernel: what
+        mz_search_move_injected enqueues when no single step is timed), bracketed by two events"""
         import ctypes
         N = self.wl['N']
-        ms = [self.hip_events.elapsed_ms(ctypes.c_void_p(ev[0]), ctypes.c_void_p(ev[2 * (N - 2) + 1])) / (N - 1)
-              for ev in self.run_sets]
+        ms = [self.hip_events.elapsed_ms(ctypes.c_void_p(ev[0]), ctypes.c_void_p(ev[2 * (N - 2) + 1])) for ev in self.run_sets]
         return float(np.mean(ms)) * 1e-3 if ms else None
 
 
@@ -456,6 +455,28 @@ def timed_region(move, steps, warmup, world, with_net, event_every=10, sync_ever
     return elapsed, int(c1[0] - c0[0]), int(c1[1] - c0[1])
 
 
+def tree_roofline(move, wl, name, mean_d, cost):
+    """HBM roofline of the tree kernels of an injected move: the one launch that runs all N simulations
+    (run_injected_kernel, the default), with the launch-per-simulation kernel (step_kernel) timed beside it."""
+    bytes_sim = bytes_per_simulation(wl['A'], mean_d, wl['A'])
+    uncost = lambda t: max(t - cost, 0.5 * t)
+    run = uncost(move.run_durations())
+    pair = move.step_durations()
+    bytes_launch = move.trees_per_launch * wl['N'] * bytes_sim
+    traffic, traffic_src = measured_traffic(name, 'run_injected_kernel')
+    out = {'bound': 'hbm', 'kernel': 'run_injected_kernel', 'achieved': bytes_launch / run / 1e9, 'peak': HBM_PEAK_GBS,
+           'unit': 'GB/s', 'frac': bytes_launch / run / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
+           'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
+           'avg_launch_us': run * 1e6, 'event_record_cost_us': cost * 1e6, 'bytes_per_launch': bytes_launch,
+           'simulations_per_launch': wl['N'], 'us_per_simulation': run * 1e6 / wl['N'], 'mean_path_len': mean_d}
+    if pair is not None:
+        step = uncost(pair)
+        step_bytes = move.trees_per_launch * bytes_sim
+        out['launch_per_simulation'] = {'kernel': 'step_kernel', 'avg_launch_us': step * 1e6, 'bytes_per_launch': step_bytes,
+                                        'achieved': step_bytes / step / 1e9, 'frac': step_bytes / step / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def tree_roofline_leg(name, device, steps, seed):
     """The tree kernels alone (injected network outputs) at one of BASELINE.json's synthetic shapes: the
     north star's HBM-roofline target is about THESE launches.  One native call enqueues a move; the fused step
@@ -468,19 +489,9 @@ def tree_roofline_leg(name, device, steps, seed):
     elapsed, sims, sum_d = timed_region(move, steps, 1, 1, False, event_every=max(2, steps))
     assert sims == steps * wl['T'] * wl['N'], (sims, steps, wl)
     mean_d = sum_d / sims
-    bytes_launch = wl['T'] * bytes_per_simulation(wl['A'], mean_d, wl['A'])
-    pair = move.step_durations()
-    avg = max(pair - cost, 0.5 * pair)
-    in_run = move.run_durations()
-    traffic, traffic_src = measured_traffic(name, 'step_kernel')
-    out = {'workload': name, 'kernel': 'step_kernel', 'bound': 'hbm', 'trees': wl['T'], 'actions': wl['A'],
-           'simulations_per_move': wl['N'], 'steps': steps, 'bytes_per_launch': bytes_launch,
-           'avg_launch_us': avg * 1e6, 'event_pair_us': pair * 1e6, 'event_record_cost_us': cost * 1e6,
-           'us_per_step_in_run': None if in_run is None else in_run * 1e6,
-           'achieved_GBps': bytes_launch / avg / 1e9, 'peak_GBps': HBM_PEAK_GBS,
-           'frac': bytes_launch / avg / 1e9 / HBM_PEAK_GBS, 'mean_path_len': mean_d,
-           'simulations_per_sec': sims / elapsed, 'ms_per_move': elapsed / steps * 1e3,
-           'traffic': traffic, 'traffic_source': traffic_src}
+    out = tree_roofline(move, wl, name, mean_d, cost)
+    out.update({'workload': name, 'trees': wl['T'], 'actions': wl['A'], 'simulations_per_move': wl['N'], 'steps': steps,
+                'simulations_per_sec': sims / elapsed, 'ms_per_move': elapsed / steps * 1e3})
     for l in move.lanes:
         l['pool'].close()
     del move
@@ -503,6 +514,8 @@ def main():
     ap.add_argument('--run-mode', type=int, default=0,
                     help='TicTacToe A/B measurements: 1 = the one-launch move with agent-scope fences, 2 = a launch per '
                          'simulation (Network.set_run_mode)')
+    ap.add_argument('--lanes-per-tree', type=int, default=0,
+                    help='tree-only A/B measurements: lanes of a wavefront per tree (TreePool lanes_per_tree; 0 = its choice)')
     ap.add_argument('--job-rows', type=int, default=0, choices=[0, 16, 64],
                     help='TicTacToe A/B measurements: games per workgroup of the job kernel (Network.set_job_rows)')
     ap.add_argument('--sync-every', type=int, default=0, help='synchronise the host every n timed steps (0 = never)')
@@ -551,7 +564,7 @@ def main():
     # per-rank seeds: every rank searches different games
     stride = max(1, min(args.event_stride, wl['N'] // 4))
     move = (NetworkMove(wl, device, 1234 + rank, world, args.lanes, stride, args.run_mode, args.job_rows) if with_net
-            else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride))
+            else SyntheticTreeMove(wl, device, 1234 + rank, args.lanes, stride, args.lanes_per_tree))
     hip_events = move.hooks.ev if with_net else move.hip_events
     timed_steps = (args.steps + args.event_every - 1) // args.event_every + 1
     hip_events.reserve(timed_steps * 3 * (wl['N'] // stride + 1) + 80)
@@ -605,18 +618,9 @@ def main():
                                            'frac': tree_bytes_launch / rest / 1e9 / HBM_PEAK_GBS, 'avg_launch_us': rest * 1e6}
         network = f"{wl['net']} network, random-init weights, f32 results (1e-5 of the fp64 oracle)"
     else:
-        pair = move.step_durations()
-        avg = uncost(pair)
-        in_run = move.run_durations()
-        achieved = tree_bytes_launch / avg / 1e9
-        traffic, traffic_src = (measured_traffic(args.workload, move.dominant) if args.trees is None and args.lanes == 1
-                                else (None, None))
-        roofline = {'bound': 'hbm', 'kernel': move.dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC)', 'traffic_source': traffic_src,
-                    'avg_launch_us': avg * 1e6, 'event_pair_us': pair * 1e6, 'event_record_cost_us': record_cost * 1e6,
-                    'us_per_step_in_run': None if in_run is None else in_run * 1e6,
-                    'bytes_per_launch': tree_bytes_launch, 'mean_path_len': mean_d}
+        roofline = tree_roofline(move, wl, args.workload, mean_d, record_cost)
+        if not (args.trees is None and args.lanes == 1):
+            roofline['traffic'] = roofline['traffic_source'] = None
         # all lanes together: algorithmic bytes of every simulation of the timed region over its wall time
         extra = {'aggregate_algorithmic_GBps': sims_rank * bytes_per_simulation(wl['A'], mean_d, wl['A']) / elapsed / 1e9}
         network = 'injected outputs (tree kernels only)'

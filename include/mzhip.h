@@ -347,10 +347,12 @@ int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t* io);
  *                                  (logits when is_logits != 0, see mz_expand_backprop_logits)
  *   reward, value [N+1, T] f32 device (row 0 unused); legal/n_legal as mz_expand_roots; noise as mz_add_root_noise
  *   parent_block, action [T] i32 device workspaces (the last select's outputs)
- *   events: NULL, or HOST array of 2*(N-1) hipEvent_t; a non-NULL events[2(s-1)] is recorded before fused step s
- *           (1-based), a non-NULL events[2(s-1)+1] after it, independently of each other: a pair times one launch, the
- *           'before' of step 1 with the 'after' of step N-1 times the whole run of steps without a record in between
- *           (measurement only; a record costs stream time) */
+ *   The N simulations are ONE launch (a wavefront keeps its trees from the first simulation to the last: no launch
+ *   boundary and no other tree's depth separates two of its simulations) unless single steps are to be timed:
+ *   events: NULL, or HOST array of 2*(N-1) hipEvent_t (measurement only; a record costs stream time).  With only
+ *           events[0] and events[2(N-2)+1] set, they are recorded before and after that one launch.  Any other non-NULL
+ *           entry asks for the launch per simulation: events[2(s-1)] is then recorded before fused step s (1-based),
+ *           events[2(s-1)+1] after it. */
 int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations, const float* policy, int32_t is_logits,
                             const float* reward, const float* value, const int32_t* legal, const int32_t* n_legal,
                             const double* noise, double noise_frac, int32_t* parent_block, int32_t* action,

@@ -28,6 +28,10 @@ void mz_pool_commit_backprop(mz_pool* pool, bool with_select);
 // the next select, the last one too when `final_select`; returns the block of the first.
 int mz_pool_begin_run(mz_pool* pool, int num_simulations, bool final_select, int* out_first_block);
 void mz_pool_commit_run(mz_pool* pool, int num_simulations, bool final_select);
+// run_mcts against given outputs in one launch (mz_tree.hip, run_injected_kernel)
+int mz_pool_run_injected(mz_pool* pool, int num_simulations, bool final_select, const float* pol, bool logits,
+                         const float* reward, const float* value, size_t pol_stride, size_t rv_stride, int32_t* out_parent,
+                         int32_t* out_action);
 
 // A native move (mz_search_move) brackets its inferences with these: begin = the initial inference (mz_infer_initial's
 // arguments; hidden_block0 receives the root hidden states), after which and until end the network keeps the move's

@@ -111,6 +111,18 @@ extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations,
     MZ_TRY_(mz_pool_reset(pool));
     MZ_TRY_(mz_expand_roots_noise(pool, policy, is_logits, legal, n_legal, noise, noise_frac));
     MZ_TRY_(mz_select(pool, parent_block, action));
+    // Timing events around single fused steps ask for the launch per simulation; otherwise the N simulations are ONE
+    // launch (run_injected_kernel), bracketed by the first 'before' and the last 'after' event when they are given.
+    bool per_step = false;
+    for (int i = 1; events && i < 2 * (N - 1) - 1; ++i) per_step |= events[i] != nullptr;
+    if (!per_step) {
+        if (events && N > 1 && events[0]) MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[0]), pool->stream));
+        MZ_TRY_(mz_pool_run_injected(pool, N, false, policy + TA, is_logits != 0, reward + T, value + T, TA, T, parent_block,
+                                     action));
+        if (events && N > 1 && events[2 * (N - 2) + 1])
+            MZ_HIP(hipEventRecord(static_cast<hipEvent_t>(events[2 * (N - 2) + 1]), pool->stream));
+        return MZ_OK;
+    }
     for (int s = 1; s <= N; ++s) {
         const float* pol = policy + (size_t)s * TA;
         const float* rw = reward + (size_t)s * T;

@@ -178,6 +178,60 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void step_kernel(PoolDev
     select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
 }
 
+// run_mcts against GIVEN network outputs (agent.py:198-211 with the network replaced by arrays) in ONE launch: the body of
+// step_kernel looped over the simulations.  Nothing in a search crosses trees and a tree's group lies inside one
+// wavefront, so a wavefront keeps its trees from the first simulation to the last and no barrier, launch boundary or
+// other wavefront's deepest tree separates two of its simulations: where a launch per simulation ends with the deepest
+// of ALL trees every time, a wavefront here only ever waits for its own.  Simulation s (0-based) reads its outputs at
+// pol + s * pol_stride, reward / value + s * rv_stride and creates record nb0 + s; the last one selects only when
+// final_select is set.  Same records, statistics and selections as the launches it replaces.
+template <int G, int P, bool LOGITS>
+__global__ __launch_bounds__(kBlockThreads) void run_injected_kernel(PoolDev p, int nb0, int nsim, int final_select,
+                                                                     const float* pol, const float* reward,
+                                                                     const float* value, size_t pol_stride, size_t rv_stride,
+                                                                     int* out_parent, int* out_action) {
+    __shared__ double s_log[kLogLds];
+    MZ_TREE_LDS(G);
+    MZ_POL_LDS(G);
+    constexpr int PB = TreeLds<G>::kPB;
+    const LdsLog lds_log = stage_log_table(p, s_log);            // once for the run (a workgroup barrier: the only one)
+#pragma unroll 1
+    for (int s = 0; s < nsim; ++s) {
+        asm volatile("" ::: "memory");
+        int tx = threadIdx.x;                                    // lane geometry from an opaque copy: nothing per-lane is
+        asm volatile("" : "+v"(tx));                             // hoisted out of the loop and kept across it
+        const int gid = blockIdx.x * kBlockThreads + tx;
+        const int tree = gid / G, gl = gid % G;
+        const float* pol_s = pol + (size_t)s * pol_stride;
+        // the policy row first, with the backup's first round trip (see stage_requests)
+        constexpr int KL = EarlyStage<G>::KL;
+        const bool row_ok = tree < p.T && p.A <= TreeLds<G>::kMaxA;
+        float pv[KL];
+#pragma unroll
+        for (int j = 0; j < KL; ++j) {
+            const int k = gl + j * G;
+            pv[j] = (row_ok && k < p.A) ? pol_s[(size_t)tree * p.A + k] : 0.f;
+        }
+        const BackupInputs<G, PB> b = backup_inputs<G, PB>(p, tree, gl, pol_s, reward + (size_t)s * rv_stride,
+                                                           value + (size_t)s * rv_stride);
+        const float* pol_row = b.pol_row;
+        if (p.A <= TreeLds<G>::kMaxA) {
+#pragma unroll
+            for (int j = 0; j < KL; ++j) {
+                const int k = gl + j * G;
+                if (k < p.A) s_pol_row[k] = pv[j];
+            }
+            pol_row = s_pol_row;
+            __builtin_amdgcn_wave_barrier();                     // the row is this wavefront's own: DS order is enough
+        }
+        backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb0 + s, pol_row, b.reward, b.value, b.pf, lds_row);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s + 1 < nsim || final_select != 0) select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Root expansion (agent.py:154-160 on the root; positional priors, trap T5).  noise != NULL: add_exploration_noise
 // (agent.py:170-175) in the same pass, the arithmetic of root_noise_kernel on the prior just computed.
 template <int G, bool LOGITS>
@@ -538,6 +592,32 @@ int backprop_impl(mz_pool* pool, const float* pol, const float* reward, const fl
 }
 
 }  // namespace
+
+// Internal (mz_pool_internal.h): `num_simulations` x { expand + backup with the given outputs, next select } in one
+// launch; the pool must hold a pending selection.
+int mz_pool_run_injected(mz_pool* pool, int num_simulations, bool final_select, const float* pol, bool logits,
+                         const float* reward, const float* value, size_t pol_stride, size_t rv_stride, int32_t* out_parent,
+                         int32_t* out_action) {
+    int nb0 = 0;
+    MZ_TRY(mz_pool_begin_run(pool, num_simulations, final_select, &nb0));
+    MZ_HIP(hipSetDevice(pool->device));
+    const int grid = grid_for(pool);
+    dispatch_group_passes(pool->G, pool->P, [&](auto g, auto pp) {
+        constexpr int G = decltype(g)::value;
+        constexpr int P = decltype(pp)::value;
+        if (logits)
+            run_injected_kernel<G, P, true><<<grid, kBlockThreads, 0, pool->stream>>>(
+                pool->dev, nb0, num_simulations, final_select ? 1 : 0, pol, reward, value, pol_stride, rv_stride, out_parent,
+                out_action);
+        else
+            run_injected_kernel<G, P, false><<<grid, kBlockThreads, 0, pool->stream>>>(
+                pool->dev, nb0, num_simulations, final_select ? 1 : 0, pol, reward, value, pol_stride, rv_stride, out_parent,
+                out_action);
+    });
+    MZ_TRY(check_launch("run_injected_kernel"));
+    mz_pool_commit_run(pool, num_simulations, final_select);
+    return MZ_OK;
+}
 
 int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block) {
     if (!pool->pending) return mz::fail(MZ_ERR_STATE, "expand_backprop without a preceding select");
