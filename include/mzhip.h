@@ -100,6 +100,15 @@ int mz_add_root_noise(mz_pool_t* pool, const double* noise, double frac);
  *   out_action       [T] i32: the last action on the path (agent.py:205).
  * The selection path is kept in the pool for the following mz_expand_backprop. */
 int mz_select(mz_pool_t* pool, int32_t* out_parent_block, int32_t* out_action);
+/* The selection of ONE tree given by the caller instead of computed by mz_select: select_leaf started at a node below
+ * the root (reference agent.py:177-181 takes any node; its backpropagate then still walks up to the root, agent.py:192-196).
+ * blocks_host / actions_host (HOST, `length` entries): the chain from the root to the leaf -- entry i is the record
+ * (expanded node) and the action of the child taken in it; blocks[0] = 0, every child but the last must be expanded with
+ * blocks[i+1] as its record, the last one unvisited.  Writes that tree's path as mz_select would have, and
+ * out_parent_block[tree] / out_action[tree].  The pool must hold one tree, or a pending mz_select for all trees (whose
+ * selection of `tree` this call replaces).  MZ_ERR_INVALID_ARG if the chain is not one.  Synchronises the stream. */
+int mz_pool_set_selection(mz_pool_t* pool, int32_t tree, const int32_t* blocks_host, const int32_t* actions_host,
+                          int32_t length, int32_t* out_parent_block, int32_t* out_action);
 
 /* expand_node(leaf, all actions) + backpropagate(leaf, value) (agent.py:208-211, 192-196) for the leaf of
  * the last mz_select.  priors [T,A] f32 (masked_policy over all A actions), reward [T] f32, value [T] f32

@@ -68,6 +68,7 @@ PROTOTYPES = {
     'mz_expand_roots_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_add_root_noise': (ctypes.c_int, [c_void_p, c_void_p, c_double]),
     'mz_select': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    'mz_pool_set_selection': (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     'mz_expand_backprop': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_expand_backprop_logits': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'mz_step': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

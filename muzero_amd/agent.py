@@ -254,11 +254,36 @@ class MCTSAgent(Agent):
         noise[0, :n] = np.random.dirichlet([self.config.mcts_config.root_dirichlet_alpha] * n)
         search.pool.add_root_noise(self._dev(noise, torch.float64), self.config.mcts_config.root_exploration_fraction)
 
+    def _select_leaf_below_root(self, node: Node, min_max_stats: MinMaxStats) -> Tuple[int, Node]:
+        """agent.py:177-181 from a node below the root: the descent is made on the host with the reference's own
+        arithmetic (select_child / ucb_score: Python floats, fp32 priors widened), then the whole chain root -> node -> leaf
+        is handed to the pool as its selection (mz_pool_set_selection), so that the following backpropagate walks up to
+        the root like the reference's does."""
+        search = self._search_of(node)
+        if search.leaf_selected:
+            raise MuZeroError('a selected leaf awaits expand_node + backpropagate')
+        if not node.expanded():
+            raise MuZeroError('select_leaf needs an expanded node (agent.py:179 would return no action)')
+        chain, n = [], node
+        while n.parent is not None:                      # root -> node
+            chain.append((n.parent._block if n.parent.parent is None else n.parent._own_block(), n._action))
+            n = n.parent
+        chain.reverse()
+        action, cur = None, node
+        while cur.expanded():
+            block = cur._own_block() if cur.parent is not None else cur._block
+            action, cur = self.select_child(cur, min_max_stats)
+            chain.append((block, action))
+        search.pool.set_selection(0, [b for b, _ in chain], [a for _, a in chain])
+        search.leaf_selected = True
+        return action, cur
+
     def select_leaf(self, node: Node, min_max_stats: MinMaxStats) -> Tuple[int, Node]:
-        """agent.py:177-181 from the root: one select launch; returns (last action, leaf view)."""
+        """agent.py:177-181.  From the root: one select launch; from any other expanded node: a host descent whose path
+        the pool adopts.  Returns (last action, leaf view)."""
         search = self._search_of(node)
         if node.parent is not None:
-            raise MuZeroError('select_leaf starts at the root (the pool keeps one selection path per tree)')
+            return self._select_leaf_below_root(node, min_max_stats)
         parent_block, action = search.pool.select()
         parent_block, action = int(parent_block[0].item()), int(action[0].item())
         search.leaf_selected = True

@@ -232,6 +232,58 @@ __global__ __launch_bounds__(kBlockThreads) void run_injected_kernel(PoolDev p, 
     }
 }
 
+// mz_pool_set_selection: the selection path of ONE tree given from outside (select_leaf started below the root by the
+// drop-in agent, agent.py:177-181), written as select_tree would have written it: path entries with the slots' visit
+// counts, path length, leaf parent / action, and the leaf's slot covered by its node's prefix.  One lane; the chain is
+// validated link by link (error flag bit 4 otherwise).
+__global__ void set_selection_kernel(PoolDev p, int tree, const int* blocks, const int* actions, int len, int* out_parent,
+                                     int* out_action) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool bad = len < 1 || len > p.N + 1 || blocks[0] != 0;
+    int* hi_home = nullptr;
+    int hi_word = 0;
+    for (int i = 0; i < len && !bad; ++i) {
+        const int e = blocks[i];
+        if (e < 0 || e > p.N) {
+            bad = true;
+            break;
+        }
+        const int n = e == 0 ? p.n_root[tree] : p.A;
+        Slot* slots = f_slots(p, rec(p, tree, e));
+        int k = -1;
+        for (int j = 0; j < n; ++j)
+            if (slots[j].act == actions[i]) {
+                k = j;
+                break;
+            }
+        if (k < 0) {
+            bad = true;
+            break;
+        }
+        const Slot sl = slots[k];
+        p.path[(size_t)tree * (p.N + 1) + i] = make_int2((e << kPathShift) | k, sl.count);
+        if (i + 1 < len) {                           // an expanded child: the next record must be its own
+            if (sl.count <= 0 || (sl.child_hi & kChildMask) != blocks[i + 1]) bad = true;
+            hi_home = &slots[k].child_hi;
+            hi_word = sl.child_hi;
+        } else if (sl.count != 0) {                  // the leaf must be unvisited
+            bad = true;
+        } else {
+            out_parent[tree] = e;
+            out_action[tree] = actions[i];
+            p.path_len[tree] = len;
+            const int hi = (int)((unsigned)hi_word >> kChildBits);
+            if (i > 0 && k + 1 > hi) *hi_home = (min(k + 1, kMaxActions - 1) << kChildBits) | (hi_word & kChildMask);
+        }
+    }
+    if (bad) {
+        out_parent[tree] = -1;
+        out_action[tree] = -1;
+        p.path_len[tree] = 0;
+        atomicOr(p.err_flag, 16);
+    }
+}
+
 // Root expansion (agent.py:154-160 on the root; positional priors, trap T5).  noise != NULL: add_exploration_noise
 // (agent.py:170-175) in the same pass, the arithmetic of root_noise_kernel on the prior just computed.
 template <int G, bool LOGITS>
@@ -853,6 +905,44 @@ int mz_select(mz_pool_t* pool, int32_t* out_parent_block, int32_t* out_action) {
     });
     MZ_TRY(check_launch("select_kernel"));
     pool->select_launches++;
+    pool->pending = true;
+    return MZ_OK;
+}
+
+int mz_pool_set_selection(mz_pool_t* pool, int32_t tree, const int32_t* blocks_host, const int32_t* actions_host,
+                          int32_t length, int32_t* out_parent_block, int32_t* out_action) {
+    MZ_REQUIRE(pool != nullptr && blocks_host && actions_host && out_parent_block && out_action,
+               "pool/blocks/actions/out_parent_block/out_action is NULL");
+    MZ_REQUIRE(tree >= 0 && tree < pool->dev.T, "tree %d out of range [0,%d)", tree, pool->dev.T);
+    MZ_REQUIRE(length >= 1 && length <= pool->dev.N + 1, "path length must be in [1, %d] (got %d)", pool->dev.N + 1, length);
+    if (pool->blocks_in_use < 1) return mz::fail(MZ_ERR_STATE, "set_selection before expand_roots");
+    if (pool->blocks_in_use > pool->dev.N)
+        return mz::fail(MZ_ERR_STATE, "pool is full: %d simulations done", pool->blocks_in_use - 1);
+    // every tree needs a selection before the next backup: either one is pending for all of them already (this call
+    // replaces the one of `tree`), or the pool holds this one tree only
+    if (!pool->pending && pool->dev.T != 1)
+        return mz::fail(MZ_ERR_STATE, "set_selection on a pool of %d trees needs a pending mz_select", pool->dev.T);
+    MZ_HIP(hipSetDevice(pool->device));
+    int* dev = nullptr;
+    MZ_HIP(hipMalloc(reinterpret_cast<void**>(&dev), 2 * (size_t)length * sizeof(int)));
+    hipError_t e = hipMemcpyAsync(dev, blocks_host, (size_t)length * sizeof(int), hipMemcpyHostToDevice, pool->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dev + length, actions_host, (size_t)length * sizeof(int), hipMemcpyHostToDevice, pool->stream);
+    if (e == hipSuccess) {
+        set_selection_kernel<<<1, 64, 0, pool->stream>>>(pool->dev, tree, dev, dev + length, length, out_parent_block,
+                                                        out_action);
+        e = hipGetLastError();
+    }
+    int err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&err, pool->dev.err_flag, sizeof(int), hipMemcpyDeviceToHost, pool->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(pool->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "set_selection failed: %s", hipGetErrorString(e));
+    if (err & 16) {
+        MZ_HIP(hipMemset(pool->dev.err_flag, 0, sizeof(int)));
+        return mz::fail(MZ_ERR_INVALID_ARG, "the given path is not a root-to-leaf chain of tree %d (an action that is not a "
+                                            "child, a link that does not lead to the next record, or a visited leaf)", tree);
+    }
     pool->pending = true;
     return MZ_OK;
 }

@@ -109,6 +109,18 @@ class TreePool:
         _lib.check(self._lib.mz_select(self._h, self._parent.data_ptr(), self._action.data_ptr()))
         return self._parent, self._action
 
+    def set_selection(self, tree, blocks, actions):
+        """The selection path of one tree given from outside (mz_pool_set_selection): blocks[i] / actions[i] = the record
+        and the action taken in it, root first, the last child unvisited -> (parent_block [T], action [T])."""
+        self._sync_stream()
+        b = np.ascontiguousarray(blocks, np.int32)
+        a = np.ascontiguousarray(actions, np.int32)
+        if b.ndim != 1 or b.shape != a.shape or b.size < 1:
+            raise MuZeroError('blocks and actions must be equally long, non-empty 1-D sequences')
+        _lib.check(self._lib.mz_pool_set_selection(self._h, int(tree), b.ctypes.data, a.ctypes.data, int(b.size),
+                                                   self._parent.data_ptr(), self._action.data_ptr()))
+        return self._parent, self._action
+
     def expand_backprop(self, policy, reward, value, logits=False):
         """expand_node + backpropagate for the last select (agent.py:208-211)."""
         self._sync_stream()

@@ -739,3 +739,64 @@ def test_tictactoe_one_launch_move_equals_the_launch_per_simulation(T):
     assert results[2][0][0][live].sum() == live.sum() * N
     # on this part the four workgroups of a row block are dealt to one XCD: the L2 path is the one that ran
     assert results['fenced_in_default_mode'] == 0
+
+
+@pytest.mark.parametrize('name', ['ttt_legal_s2', 'atari_s9', 'asym_bounds_s15'])
+def test_select_leaf_from_a_node_below_the_root(name):
+    """The reference's select_leaf takes ANY node (agent.py:177-181).  Here: whenever the root's own choice is an expanded
+    child, the descent is started at THAT child (host arithmetic of select_child / ucb_score, path adopted by the pool via
+    mz_pool_set_selection) -- it must end at the leaf the reference reached from the root in the same simulation, and the
+    search statistics after all simulations must be the reference's, bit for bit (known and live value bounds, a root
+    with a non-monotone legal list)."""
+    import torch
+    from muzero_amd.agent import MCTSAgent
+    from muzero_amd.config import GameConfig, MCTSConfig, MuZeroConfig, NetworkConfig, ScalarConfig
+    from muzero_amd.exceptions import MuZeroError
+    from muzero_amd.utils import KnownBounds, MinMaxStats
+    fx = load_golden(name)
+    A, N = int(fx['A']), int(fx['N'])
+    kb = KnownBounds(minv=float(fx['known_min']), maxv=float(fx['known_max'])) if int(fx['has_bounds']) else None
+    config = MuZeroConfig(
+        game_config=GameConfig(name='synthetic', environment_class=None, environment_parameters={}, action_space_size=A,
+                               num_players=int(fx['num_players']), discount=float(fx['discount'])),
+        replay_buffer_config=None, training_config=None,
+        mcts_config=MCTSConfig(max_moves=10, root_dirichlet_alpha=1.0, root_exploration_fraction=float(fx['frac']),
+                               num_simulations=N, temperature=1.0, freezing_moves=10,
+                               default_value=float(fx['default_value'])),
+        network_config=NetworkConfig(network_class=None),
+        reward_config=ScalarConfig(known_bounds=None, support_size=None, loss_decay=0.0),
+        value_config=ScalarConfig(known_bounds=kb, support_size=None, loss_decay=0.0))
+    net = ReplayNetwork(fx)
+    agent = MCTSAgent(config=config, network=net, device='cuda')
+    root = agent.new_root()
+    mm = MinMaxStats(config.value_config.known_bounds)
+    legal = [int(a) for a in fx['legal']]
+    agent.expand_node(root, legal, net.initial_inference(np.zeros((1, 1), np.float32)).split_batch()[0])
+    noise = np.zeros((1, A))
+    noise[0] = fx['noise']
+    agent._pool.add_root_noise(torch.from_numpy(noise).cuda(), float(fx['frac']))
+    below = 0
+    for s in range(N):
+        if s == 3:                                                  # a chain that is not one is refused, nothing changes
+            with pytest.raises(MuZeroError):
+                agent._pool.set_selection(0, [0, N], [legal[0], 0])
+        first_action, first = agent.select_child(root, mm)
+        if first.expanded():
+            action, leaf = agent.select_leaf(first, mm)             # started below the root
+            below += 1
+            with pytest.raises(MuZeroError):
+                agent.select_leaf(first, mm)                        # a leaf is pending
+        else:
+            action, leaf = agent.select_leaf(root, mm)
+        assert action == int(fx['trace_action'][s]), f'simulation {s}'
+        parent_block = leaf.parent._block if leaf.parent.parent is None else leaf.parent._own_block()
+        assert parent_block == int(fx['trace_parent'][s]), f'simulation {s}'
+        assert not leaf.expanded()
+        out = net.recurrent_inference(None, None).split_batch()[0]
+        agent.expand_node(leaf, config.action_space(), out)
+        agent.backpropagate(leaf, out.value, mm)
+    assert below > N // 3
+    assert root.visit_count == N and root.value == float(fx['root_value'])
+    np.testing.assert_array_equal([root.children[a].visit_count for a in legal], fx['root_visits'][legal])
+    if kb is None:
+        assert (mm.minimum, mm.maximum) == (float(fx['mm_min']), float(fx['mm_max']))
