@@ -666,6 +666,19 @@ __device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, in
     s->q = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
 }
 
+// A child slot at expansion: count 0, prior, action -- written as the WHOLE 24-byte slot (q and the child word as zeros:
+// nobody reads them before the first backup through the slot writes them), so that a record's select half is
+// overwritten line by line and the L2 never has to fetch a line from HBM just to merge twelve new bytes into it.
+__device__ __forceinline__ void store_new_slot(Slot* s, float prior, int action) {
+    Slot v;
+    v.q = 0.0;
+    v.count = 0;
+    v.prior = prior;
+    v.child_hi = 0;
+    v.act = action;
+    *s = v;
+}
+
 // A prior the prefix argument of select_tree can rely on: finite and >= 0.
 __device__ __forceinline__ bool regular_prior(float x) { return x >= 0.f && x <= 3.4028234663852886e38f; }
 
@@ -730,12 +743,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             const int s1 = sorted_slot(A, gl, pr, [&](int j) { return __shfl(pr, j, G); });
             if (gl >= 1) slot = s1;
         }
-        if (active && gl < A) {
-            Slot* s = f_slots(p, rec(p, tree, nb)) + slot;
-            s->count = 0;
-            s->prior = pr;
-            s->act = gl;
-        }
+        if (active && gl < A) store_new_slot(f_slots(p, rec(p, tree, nb)) + slot, pr, gl);
     } else if (lds_row != nullptr && A <= L::kMaxA) {
         // priors staged in the group's LDS row (softmax terms summed there in NumPy's order)
         for (int k = gl; k < A; k += G) lds_row[k] = !active ? 0.f : LOGITS ? expf(pol_row[k]) : pol_row[k];
@@ -754,12 +762,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             const float pr = lds_row[k];
             int slot = k;
             if (sorted && k >= 1) slot = sorted_slot_lds(A, k, pr, lds_row);
-            if (active) {
-                Slot* s = slots + slot;
-                s->count = 0;
-                s->prior = pr;
-                s->act = k;
-            }
+            if (active) store_new_slot(slots + slot, pr, k);
         }
         __builtin_amdgcn_wave_barrier();
     } else {

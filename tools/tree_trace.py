@@ -2,7 +2,7 @@
 """Profiling aid: phase times inside the tree kernels from an experiment build of the library.
 
     hipcc ... -DMZ_TREE_TRACE -> tools/micro/libmzhip_trace.so (tools/micro/build_trace.sh), then
-    MZ_LIB=tools/micro/libmzhip_trace.so python tools/tree_trace.py <workload> [lanes]
+    MZ_LIB=tools/micro/libmzhip_trace.so python tools/tree_trace.py <workload> [lanes] [run]
 """
 import ctypes, os, sys
 import numpy as np, torch
@@ -28,7 +28,8 @@ def main():
     W, PH = 1 << 15, 12
     out = np.zeros((W, 2 * PH), np.uint32)
     read = lambda: lib.mz_debug_tree_trace(ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(out.nbytes))
-    for m in range(2):
+    run = len(sys.argv) > 3 and sys.argv[3] == 'run'      # the one-launch run (run_injected_kernel), logits like bench.py
+    for m in range(2 if not run else 0):
         pool.reset(); pool.expand_roots(pol[0]); pool.add_root_noise(noise, 0.25); pool.select()
         read()
         for s in range(N - 1):
@@ -36,6 +37,10 @@ def main():
         read()
         pool.expand_backprop(pol[N], rewards[N], values[N])
     launches = N - 1
+    if run:
+        pool.search_injected(logits, rewards, values, noise=noise, frac=0.25, logits=True); torch.cuda.synchronize(); read()
+        pool.search_injected(logits, rewards, values, noise=noise, frac=0.25, logits=True); torch.cuda.synchronize(); read()
+        launches = N
     used = out[:, PH + 1] > 0
     nw = int(used.sum())
     print(f'{name} lanes={lanes}: {nw} wavefronts, {launches} launches; shader clocks per wavefront and launch')
