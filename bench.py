@@ -304,6 +304,12 @@ class NetworkMove:
             self.hooks.sampled = self.hooks.sampled[:1]
             self.evals_per_launch = self.trees_per_launch * wl['N']
         self.gather = TrajectoryGather(T, A, device) if world > 1 else None
+        self.job_ticks0 = (0, 0)
+
+    def mark_jobs(self):
+        """start of the timed region: the job-phase counters so far (TicTacToe one-launch move)"""
+        if self.dominant == 'ttt_run_kernel':
+            self.job_ticks0 = self.net.run_info_all()[2:]
 
     def run(self, timed_events=False):
         events = self.hooks.new_set() if timed_events else None
@@ -431,6 +437,8 @@ def timed_region(move, steps, warmup, world, with_net, event_every=10, sync_ever
         move.run_sets.clear()
     torch.cuda.synchronize()
     c0 = move.counters()
+    if with_net:
+        move.mark_jobs()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -603,6 +611,19 @@ def main():
                     'avg_launch_us': k1 * 1e6, 'event_pair_us': k1_raw * 1e6, 'event_record_cost_us': record_cost * 1e6,
                     'flops_per_launch': flops_launch, 'mfma_operands': mfma_dtype,
                     'executed_mfma_tflops': executed, 'executed_frac': executed / peak}
+        if move.dominant == 'ttt_run_kernel':
+            # the job phase inside the launch (what ttt_ring_kernel was as a launch of its own until round 2): the
+            # workgroups' own wall-clock stamps around their jobs, averaged over workgroups and simulations
+            _, _, ticks, jobs = move.net.run_info_all()
+            t0, j0 = move.job_ticks0
+            if jobs > j0:
+                job_s = (ticks - t0) / (jobs - j0) * 1e-8
+                job_flops = move.trees_per_launch * 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
+                roofline['job_phase'] = {
+                    'what': 'the jobs (conv taps, Dense, reward dots, prediction-conv terms: 2,310,656 FLOP per evaluation) of '
+                            'one simulation inside the launch; mean over workgroups of their own 100 MHz wall-clock stamps',
+                    'avg_us': job_s * 1e6, 'achieved': job_flops / job_s / 1e12, 'frac': job_flops / job_s / 1e12 / peak,
+                    'executed_frac': 3 * job_flops / job_s / 1e12 / peak}
         one_launch = move.one_launch
         rest_name = ('after_fused_kernel_us' if one_launch else
                      'head_and_tree_step_kernel_us' if wl['net'] == 'tictactoe' else 'tree_step_kernel_us')

@@ -219,15 +219,16 @@ int mz_net_set_mid_event(mz_net_t* net, void* hip_event);
  * same launch with full agent-scope fences at every meeting of a row block's workgroups (the path taken by itself when
  * they are found on different XCDs); 2 = a launch per simulation (the kernels of mz_infer_recurrent_step).  All three
  * give bit-identical trees and outputs.
- * mz_debug_run_info: out2_host[0] = row-block runs that took the fence path since the handle was created, [1] = row-block
- * runs in all.  Synchronises. */
+ * mz_debug_run_info: out4_host[0] = row-block runs that took the fence path since the handle was created, [1] = row-block
+ * runs in all, [2] = 100 MHz wall-clock ticks the workgroups of the one-launch move spent inside their jobs, [3] = the
+ * number of jobs (workgroups x simulations) those ticks belong to.  Synchronises. */
 int mz_debug_set_run_mode(mz_net_t* net, int32_t mode);
 /* Test / measurement switch of the TicTacToe job kernel's shape: rows = 0 (default) chooses by batch size -- 16 games x one
  * board cell per workgroup up to 1792 games, 64 games x a group of cells beyond --, 16 or 64 force that shape.  The two
  * shapes sum the prediction conv's per-cell terms in different orders: results agree to float rounding (both are held to
  * 1e-5 of the fp64 oracle), not bit for bit. */
 int mz_debug_set_job_rows(mz_net_t* net, int32_t rows);
-int mz_debug_run_info(mz_net_t* net, int64_t* out2_host);
+int mz_debug_run_info(mz_net_t* net, int64_t* out4_host);
 
 /* Network.initial_inference (network.py:221-229) fused with split_batch's to_scalar (network.py:165-174).
  *   observation [B, obs] f32 (TicTacToe 27 = 3x3x3 NHWC, CartPole 4, Atari-shaped 256 = 2x128);

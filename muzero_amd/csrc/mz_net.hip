@@ -1051,7 +1051,8 @@ constexpr int kRunMaxRowBlocks = 4096;               // 262144 games per launch
 struct RunSync {
     unsigned long long* arrive;     // [row block]: (epoch << 20) + arrivals of this launch
     unsigned* xcc_mask;             // [row block]: bits of the XCC ids its workgroups have run on
-    unsigned* stats;                // [0] row-block runs that took the fence path, [1] row-block runs
+    unsigned long long* stats;      // [0] row-block runs that took the fence path, [1] row-block runs, [2] 100 MHz wall-clock
+                                    // ticks workgroups spent in their jobs, [3] the jobs those ticks are of (measurement)
     unsigned long long epoch_base;  // epoch << kRunEpochShift of this launch
     int force_fences;               // tests: take the agent-scope fence path whatever the placement
 };
@@ -1143,20 +1144,25 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
     __syncthreads();
     const bool fenced = s_flags[2] != 0;
     if (threadIdx.x == 0 && job == 0) {
-        atomicAdd(sync.stats + 1, 1u);
-        if (fenced) atomicAdd(sync.stats, 1u);
+        atomicAdd(sync.stats + 1, 1ull);
+        if (fenced) atomicAdd(sync.stats, 1ull);
     }
     const int hrow0 = rb * 64 + job * 16;
     MZ_RUN_STAMP_DECL;
+    long long job_ticks = 0;                         // thread 0: wall-clock ticks inside the jobs (mz_debug_run_info)
+    int jobs_done = 0;
 #pragma unroll 1
     for (int i = 0; i < nsim && alive; ++i) {
         asm volatile("" ::: "memory");
         const int nb = nb0 + i;
         const bool traced = trace_parent != nullptr;
+        const long long job_t0 = wall_clock64();
         ttt_ring_body<SPLIT_IO>(w, p.T, hidden_base, parent_block, block_stride, action,
                                 hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
                                 traced ? trace_parent + (size_t)i * p.T : nullptr,
                                 traced ? trace_action + (size_t)i * p.T : nullptr, true);
+        job_ticks += wall_clock64() - job_t0;
+        ++jobs_done;
         MZ_RUN_STAMP(0);
         target += 4;
         meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags + 1);
@@ -1198,6 +1204,10 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
                 MZ_RUN_STAMP(5);
             }
         }
+    }
+    if (threadIdx.x == 0 && jobs_done > 0) {
+        atomicAdd(sync.stats + 2, (unsigned long long)job_ticks);
+        atomicAdd(sync.stats + 3, (unsigned long long)jobs_done);
     }
 }
 
@@ -3205,7 +3215,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
     if (kind == MZ_NET_TICTACTOE) {
-        const size_t bytes = (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned)) + 2 * sizeof(unsigned);
+        const size_t bytes = (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned)) +
+                             4 * sizeof(unsigned long long);
         e = hipMalloc(reinterpret_cast<void**>(&net->run_sync), bytes);
         if (e == hipSuccess) e = hipMemset(net->run_sync, 0, bytes);
         if (e != hipSuccess) {
@@ -3499,18 +3510,17 @@ int mz_debug_set_job_rows(mz_net_t* net, int32_t rows) {
     return MZ_OK;
 }
 
-int mz_debug_run_info(mz_net_t* net, int64_t* out2_host) {
-    MZ_REQUIRE(net != nullptr && out2_host != nullptr, "net/out2_host is NULL");
-    out2_host[0] = out2_host[1] = 0;
+int mz_debug_run_info(mz_net_t* net, int64_t* out4_host) {
+    MZ_REQUIRE(net != nullptr && out4_host != nullptr, "net/out4_host is NULL");
+    for (int i = 0; i < 4; ++i) out4_host[i] = 0;
     if (!net->run_sync) return MZ_OK;
     MZ_HIP(hipSetDevice(net->device));
     MZ_HIP(hipStreamSynchronize(net->stream));
-    unsigned host[2] = {0, 0};
+    unsigned long long host[4] = {0, 0, 0, 0};
     const char* base = reinterpret_cast<const char*>(net->run_sync) +
                        (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned));
     MZ_HIP(hipMemcpy(host, base, sizeof(host), hipMemcpyDeviceToHost));
-    out2_host[0] = host[0];
-    out2_host[1] = host[1];
+    for (int i = 0; i < 4; ++i) out4_host[i] = (int64_t)host[i];
     return MZ_OK;
 }
 
@@ -3554,7 +3564,7 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         RunSync sync;
         sync.arrive = net->run_sync;
         sync.xcc_mask = reinterpret_cast<unsigned*>(net->run_sync + kRunMaxRowBlocks);
-        sync.stats = sync.xcc_mask + kRunMaxRowBlocks;
+        sync.stats = reinterpret_cast<unsigned long long*>(sync.xcc_mask + kRunMaxRowBlocks);
         sync.epoch_base = (++net->run_epoch) << kRunEpochShift;
         sync.force_fences = net->run_mode == 1;
         const int grid = 32 * (((T + 63) / 64 + 7) / 8);

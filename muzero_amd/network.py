@@ -273,9 +273,13 @@ class Network:
 
     def run_info(self):
         """mz_debug_run_info -> (row-block runs that took the fence path, row-block runs); synchronises."""
-        out = np.zeros(2, np.int64)
+        return self.run_info_all()[:2]
+
+    def run_info_all(self):
+        """-> (fence-path row-block runs, row-block runs, 100 MHz ticks spent inside jobs, jobs); synchronises."""
+        out = np.zeros(4, np.int64)
         _lib.check(self._lib.mz_debug_run_info(self._h, out.ctypes.data))
-        return int(out[0]), int(out[1])
+        return tuple(int(x) for x in out)
 
     def check_range(self) -> None:
         """Raises MuZeroError if an inference since the last check saturated an activation (see include/mzhip.h,
