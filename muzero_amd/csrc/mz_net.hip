@@ -174,8 +174,9 @@ struct TttDev {
     const float* pred_conv_s;   // [9 cells]
     int job_cells[4][3];        // the cells of job j, -1 = none
     const int4* ring_desc;      // the jobs as stages of ttt_ring_kernel: (kind, cell, weight matrix, source cell)
-    int ring_first[15];         // job j owns descriptors [ring_first[j], ring_first[j+1]): j = 0..3 the four cell groups of
-                                // the 64-game workgroups, j = 5 + c the single cell c of the 16-game workgroups
+    int ring_first[20];         // job j owns descriptors [ring_first[j], ring_first[j+1]): j = 0..3 the four cell groups of
+                                // the 64-game workgroups, j = 5 + c the single cell c of the 16-game workgroups,
+                                // j = 15..18 the four cell groups inside ttt_run_kernel
     float dyn_reward_b, pred_value_b;
     int* range_flag;            // raised when a kernel splits a value outside the split-f16 domain (mz_net_status)
 };
@@ -301,7 +302,22 @@ __device__ __forceinline__ void load_bw(BFragW& b, const float* __restrict__ Ws,
 // in between; only the two stages whose tile comes from an epilogue (Dense, prediction conv) start cold behind an
 // end-of-stage barrier.  acx (the cross terms) is folded into acc once per accumulation, not once per stage.
 // Stage kinds of the descriptors (TttDev::ring_desc: .x kind, .y cell, .z weight matrix, .w source cell):
-constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3, kRingPred = 4;
+constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3, kRingPred = 4, kRingPredRemote = 5;
+// More of the descriptors:
+//   * a prediction-conv stage's .w = (slice << 8) | flags: kPredFresh = the partial starts with this cell (else it joins the
+//     job's running sum in sAccP), kPredStore = the sum so far is this job's partial of `slice` (one 128-float slice of a
+//     game's partials row; the head adds the slices in index order, so WHO computes a slice does not change a bit);
+//   * kRingPredRemote (ttt_run_kernel only): the prediction-conv term of a cell whose hidden' rows ANOTHER workgroup of the
+//     row block produced in this simulation -- the three-corner job hands two of its three prediction-conv stages to the
+//     two-edge jobs, which would otherwise wait for it (job balance).  Its tile is gathered from the
+//     rows just written (the producer raises a per-cell flag once its stores are complete, the consumer looks at the flag
+//     before it requests the rows), everything else is a prediction-conv stage;
+//   * a tap's .x carries in bits 8..15 (1 + the cell whose hidden' rows are complete by then and whose flag this stage
+//     raises: the second tap of the producer's next cell) and a first tap's in bits 16.. (1 + the cell whose flag this
+//     stage takes a first look at: the consumer's last own cell, five stages before it needs the answer), 0 = none.
+constexpr int kPredFresh = 1, kPredStore = 2;
+constexpr long long kRunSpinTicks = 100000000;       // bounded waits of ttt_run_kernel: 1 s of the 100 MHz wall clock
+__device__ __forceinline__ bool ring_gathered(int kind) { return kind <= kRingTapLast || kind == kRingPredRemote; }
 
 // a gathered tile: the staged 16 bytes of every thread (four per thread: rows idx / 32, 16-byte column idx % 32) into LDS
 template <bool SPLIT_IO, int MB>
@@ -333,9 +349,12 @@ template <bool SPLIT_IO, int MB = 4>
 __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const float* in_base, const int* parent_block,
                                               long block_stride, const int* action, float* out_hidden, float* ppart,
                                               float* rpart, int rb, int job, int* trace_parent, int* trace_action,
-                                              bool coh = false) {
+                                              bool coh = false, unsigned long long* cell_flags = nullptr,
+                                              unsigned long long flag_value = 0, int* err_flag = nullptr) {
     constexpr int ROWS = 16 * MB, TILE = ROWS * kLdW;
-    const int djob = MB == 4 ? job : 5 + job;        // descriptor list: the four cell groups, then the nine cells
+    // descriptor list: the four cell groups (as launches of their own), the nine cells, the four cell groups inside
+    // ttt_run_kernel (cell_flags != nullptr: two prediction-conv stages change workgroups)
+    const int djob = MB == 1 ? 5 + job : cell_flags != nullptr ? 15 + job : job;
     __shared__ __attribute__((aligned(16))) _Float16 sRing[3 * TILE];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
@@ -408,9 +427,8 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
 #pragma unroll
     for (int m = 0; m < MB; ++m) lact[m] = sAct[16 * m + n16];
     f32x4 acc[MB], acx[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) sAccP[m * kThreadsW + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 af[2][MB][2];                              // activation fragments: ring over k-steps, carried across stages
+    unsigned long long flag_seen = 0;                // thread 0: the flag of the remote cell as requested ahead of its use
     int cur = 0, nxt = 1;                            // ring positions of this stage's and the next stage's tile
     Desc Dc = D0, Dn = desc[1], Dn2 = desc[2];
     MZ_TRACE_DECL;
@@ -424,18 +442,31 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4, lcol = wave * 16 + 4 * g;
-        const int kind = Dc.x, cell = Dc.y;
+        const int kind = Dc.x & 0xff, cell = Dc.y;
         const bool has_next = d + 1 < d1;
         const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on: a scalar load with the
                                                                 // whole stage to arrive in
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
         const float4* wnext = wlane + (size_t)(has_next ? Dn.z : Dc.z) * 4096;
-        const bool primed = d > 0 && kind <= kRingTapLast;       // af[0] holds this stage's first fragments already
-        const bool commit = has_next && Dn.x <= kRingTapLast;    // the next stage is a gathered tap: its tile is committed
+        const bool primed = d > 0 && ring_gathered(kind);        // af[0] holds this stage's first fragments already
+        const bool commit = has_next && ring_gathered(Dn.x & 0xff);     // the next stage's tile is gathered: it is committed
                                                                  // after k-step 1, a barrier follows, k-step 3 reads its
                                                                  // first fragments
-        const bool load2 = d + 2 < d1 && Dn2.x <= kRingTapLast;  // request the tile of the stage after the next
-        const int src2 = Dn2.w * 128;
+        const bool load2 = d + 2 < d1 && ring_gathered(Dn2.x & 0xff);   // request the tile of the stage after the next
+        const bool remote2 = (Dn2.x & 0xff) == kRingPredRemote;  // ... from this simulation's hidden' rows of cell Dn2.y
+        const int src2 = remote2 ? Dn2.y * 128 : Dn2.w * 128;
+        if (MB == 4 && cell_flags != nullptr && kind == kRingTapFirst && (Dc.x >> 16) != 0 && tid == 0)
+            flag_seen = __hip_atomic_load(cell_flags + ((Dc.x >> 16) - 1 == 2 ? 0 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MB == 4 && remote2) {
+            // the remote prediction-conv stage is a job's last gathered stage: from here on the gather pointers are the
+            // rows row0 + r of THIS simulation's block, as their producer stored them (outside the MFMA section, which
+            // stays the scheduling region it was)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int idx = tid + kThreadsW * i, r = idx >> 5, c4 = idx & 31;
+                sptr[i] = out_hidden + (size_t)(row0 + r) * 1152 + c4 * 4;
+            }
+        }
         float bt[3];
         if (kind == kRingTapFirst) {
             // first tap of a cell: its bias table for all nine actions and its reward weights, requested ahead of this
@@ -496,6 +527,14 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
                 if (s == 1 && commit) {              // the tile requested during the previous stage, then the barrier
                     ring_commit<SPLIT_IO, MB>(sRing + nxt * TILE, stg, svalid, tid, vmax);
                     __syncthreads();
+                    // A cell's SECOND tap may carry the cell whose hidden' rows this workgroup stored two stages ago (in
+                    // the epilogue of that cell's Dense stage).  The weight fragments of this stage were requested during
+                    // the stage in between, i.e. AFTER those stores; every wave that is past this barrier has waited for
+                    // them, and vector memory operations retire in order (one vmcnt for loads and stores on this part):
+                    // the rows are in the XCD's L2 -- raise the cell's flag.
+                    if (MB == 4 && cell_flags != nullptr && ((Dc.x >> 8) & 0xff) != 0 && tid == 0)
+                        __hip_atomic_fetch_max(cell_flags + (((Dc.x >> 8) & 0xff) - 1 == 2 ? 0 : 1), flag_value,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (s == 2 && load2) {               // the tile two stages ahead
 #pragma unroll
@@ -526,12 +565,31 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
                 *reinterpret_cast<uint2*>(row + 128) = l;
             }
             MZ_TRACE_NW(3);                          // epilogue
+            if (MB == 4 && cell_flags != nullptr && d + 3 < d1 && (Dn3.x & 0xff) == kRingPredRemote && tid == 0) {
+                // the rows of the remote prediction-conv stage are requested during the next stage: their producer must
+                // have raised the cell's flag (it did so a dozen stages ago unless something is badly out of step)
+                const unsigned long long* flag = cell_flags + (Dn3.y == 2 ? 0 : 1);
+                const long long t0 = wall_clock64();
+                while ((long long)(flag_seen - flag_value) < 0) {        // (as a rule the early look has seen it already)
+                    flag_seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((long long)(flag_seen - flag_value) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > kRunSpinTicks) {
+                        atomicOr(err_flag, 8);
+                        break;
+                    }
+                }
+            }
             __syncthreads();
             MZ_TRACE_NW(4);                          // barrier
         } else if (kind == kRingDense) {     // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             fold4(acc, acx);
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
-            _Float16* sH = sRing + nxt * TILE;
+            // The Dense output tile is the next stage's (the cell's prediction-conv term) -- unless that term is computed
+            // elsewhere and the next stage is the first tap of another cell, whose gathered tile already sits in `nxt`:
+            // then the rows are staged for the copy-out in THIS stage's tile, once every wave is done reading it.
+            if (commit) __syncthreads();
+            _Float16* sH = sRing + (commit ? cur : nxt) * TILE;
             {
                 const float4 bq = *reinterpret_cast<const float4*>(sBias + 10 * 128 + lcol);
                 const float4 rw = *reinterpret_cast<const float4*>(sBias + 9 * 128 + lcol);
@@ -582,18 +640,21 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
                 }
             }
             MZ_TRACE_NW(5);                          // after the barrier
-        } else if (kind == kRingPred) {      // this cell's term of the prediction conv (games/tictactoe.py:201) joins sAccP
+        } else if (kind >= kRingPred) {      // this cell's term of the prediction conv (games/tictactoe.py:201)
             fold4(acc, acx);
+            const int pflags = Dc.w & 0xff;
+            if (!(pflags & kPredFresh)) {            // joins the job's running sum
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const float4 q = sAccP[m * kThreadsW + tid];
-                acc[m] += f32x4{q.x, q.y, q.z, q.w};
+                for (int m = 0; m < MB; ++m) {
+                    const float4 q = sAccP[m * kThreadsW + tid];
+                    acc[m] += f32x4{q.x, q.y, q.z, q.w};
+                }
             }
-            if (has_next) {
+            if (!(pflags & kPredStore)) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) sAccP[m * kThreadsW + tid] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            } else {              // end of the job: one partial per (game, job)
-                float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;      // MB == 1: job = cell
+            } else {              // one 128-float slice of the games' partials rows is complete
+                float* const pjob = ppart + (size_t)row0 * 1152 + (Dc.w >> 8) * 128;
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                     if ((rowmask >> (16 * m + n16)) & 1ull)
@@ -868,8 +929,20 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 t = bn;
+            if (NP == 6) {
+                // the 64-game jobs as launches of their own keep the corners' terms in slices of their own (4: cell 2,
+                // 5: cell 6); ttt_run_kernel computes them in the workgroups of slices 1 and 2 and adds them there --
+                // the same two additions, made here first, give the same bits
 #pragma unroll
-            for (int c = 0; c < NP; ++c) {
+                for (int c = 1; c <= 2; ++c) {
+                    v[i][c].x += v[i][c + 3].x;
+                    v[i][c].y += v[i][c + 3].y;
+                    v[i][c].z += v[i][c + 3].z;
+                    v[i][c].w += v[i][c + 3].w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < (NP == 6 ? 4 : NP); ++c) {
                 t.x += v[i][c].x;
                 t.y += v[i][c].y;
                 t.z += v[i][c].z;
@@ -1045,12 +1118,13 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
 // set by an atomic max at the first meeting: nothing has to be cleared between launches, and a launch that gave up leaves
 // nothing behind that the next one could take for its own arrivals.
 constexpr int kRunEpochShift = 20;
-constexpr long long kRunSpinTicks = 100000000;       // 1 s of s_memrealtime
 
 constexpr int kRunMaxRowBlocks = 4096;               // 262144 games per launch
 struct RunSync {
     unsigned long long* arrive;     // [row block]: (epoch << 20) + arrivals of this launch
     unsigned* xcc_mask;             // [row block]: bits of the XCC ids its workgroups have run on
+    unsigned long long* cell_flags; // [row block][2]: (epoch << 20) + 1 + the last simulation whose hidden' rows of the
+                                    // corners 2 / 6 are complete (the prediction-conv stages that change workgroups)
     unsigned long long* stats;      // [0] row-block runs that took the fence path, [1] row-block runs, [2] 100 MHz wall-clock
                                     // ticks workgroups spent in their jobs, [3] the jobs those ticks are of (measurement)
     unsigned long long epoch_base;  // epoch << kRunEpochShift of this launch
@@ -1160,7 +1234,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
         ttt_ring_body<SPLIT_IO>(w, p.T, hidden_base, parent_block, block_stride, action,
                                 hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
                                 traced ? trace_parent + (size_t)i * p.T : nullptr,
-                                traced ? trace_action + (size_t)i * p.T : nullptr, true);
+                                traced ? trace_action + (size_t)i * p.T : nullptr, true, sync.cell_flags + 2 * rb,
+                                sync.epoch_base + (unsigned long long)i + 1, p.err_flag);
         job_ticks += wall_clock64() - job_t0;
         ++jobs_done;
         MZ_RUN_STAMP(0);
@@ -3000,28 +3075,9 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             for (int ci = 0; ci < 3; ++ci) t.job_cells[j][ci] = kJobCells[j][ci];
         // their stages for the ring kernel: (kind, cell, weight matrix, source cell); matrices 0..8 = conv taps,
         // 9 = Dense, 10 + c = prediction conv of cell c (consecutive in the packed buffer, checked below)
-        for (int j = 0; j < 4; ++j) {
-            t.ring_first[j] = (int)desc.size() / 4;
-            for (int ci = 0; ci < 3; ++ci) {
-                const int c = kJobCells[j][ci];
-                if (c < 0) continue;
-                int valid[9], nv = 0;
-                for (int tp = 0; tp < 9; ++tp) {
-                    const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
-                    if (ni >= 0 && ni < 3 && nj >= 0 && nj < 3) valid[nv++] = tp;
-                }
-                for (int i = 0; i < nv; ++i) {
-                    const int tp = valid[i];
-                    push(i == 0 ? kRingTapFirst : i == nv - 1 ? kRingTapLast : kRingTap, c, tp,
-                         (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
-                }
-                push(kRingDense, c, 9, 0);
-                push(kRingPred, c, 10 + c, 0);
-            }
-        }
-        t.ring_first[4] = (int)desc.size() / 4;
-        for (int c = 0; c < 9; ++c) {                 // the nine single-cell jobs of the 16-game workgroups
-            t.ring_first[5 + c] = (int)desc.size() / 4;
+        // one cell: its valid taps, Dense, and (pred_w >= 0) its prediction-conv stage with .w = pred_w; `signal` = the cell
+        // whose flag the second tap raises, `look` = the cell whose flag the first tap takes an early look at (-1: none)
+        auto emit_cell = [&](int c, int pred_w, int signal, int look = -1) {
             int valid[9], nv = 0;
             for (int tp = 0; tp < 9; ++tp) {
                 const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
@@ -3029,13 +3085,55 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             }
             for (int i = 0; i < nv; ++i) {
                 const int tp = valid[i];
-                push(i == 0 ? kRingTapFirst : i == nv - 1 ? kRingTapLast : kRingTap, c, tp,
+                push(i == 0 ? (kRingTapFirst | ((look + 1) << 16)) : i == nv - 1 ? kRingTapLast : (kRingTap | (i == 1 ? (signal + 1) << 8 : 0)), c, tp,
                      (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
             }
             push(kRingDense, c, 9, 0);
-            push(kRingPred, c, 10 + c, 0);
+            if (pred_w >= 0) push(kRingPred, c, 10 + c, pred_w);
+        };
+        auto pw = [](int slice, int flags) { return (slice << 8) | flags; };
+        // Slices of a game's partials row (the head adds them in index order): 0 = cells {4, 0}, 1 = {1, 3}, 2 = {5, 7},
+        // 3 = {8}, 4 = {2}, 5 = {6} for the 64-game jobs -- the corners' terms stay apart so that it does not matter, to
+        // the last bit, which workgroup computes them; slice c = cell c for the 16-game jobs.
+        // (a) the 64-game jobs as launches of their own
+        t.ring_first[0] = (int)desc.size() / 4;
+        emit_cell(4, pw(0, kPredFresh), -1);
+        emit_cell(0, pw(0, kPredStore), -1);
+        t.ring_first[1] = (int)desc.size() / 4;
+        emit_cell(1, pw(1, kPredFresh), -1);
+        emit_cell(3, pw(1, kPredStore), -1);
+        t.ring_first[2] = (int)desc.size() / 4;
+        emit_cell(5, pw(2, kPredFresh), -1);
+        emit_cell(7, pw(2, kPredStore), -1);
+        t.ring_first[3] = (int)desc.size() / 4;
+        emit_cell(2, pw(4, kPredFresh | kPredStore), -1);
+        emit_cell(6, pw(5, kPredFresh | kPredStore), -1);
+        emit_cell(8, pw(3, kPredFresh | kPredStore), -1);
+        t.ring_first[4] = (int)desc.size() / 4;
+        // (b) the nine single-cell jobs of the 16-game workgroups
+        for (int c = 0; c < 9; ++c) {
+            t.ring_first[5 + c] = (int)desc.size() / 4;
+            emit_cell(c, pw(c, kPredFresh | kPredStore), -1);
         }
         t.ring_first[14] = (int)desc.size() / 4;
+        // (c) the 64-game jobs inside ttt_run_kernel: the corners 2 and 6 keep their taps and Dense in job 3, which raises
+        // their flags at the first tap of its next cell; their prediction-conv terms end jobs 1 and 2
+        t.ring_first[15] = (int)desc.size() / 4;
+        emit_cell(4, pw(0, kPredFresh), -1);
+        emit_cell(0, pw(0, kPredStore), -1);
+        t.ring_first[16] = (int)desc.size() / 4;
+        emit_cell(1, pw(1, kPredFresh), -1);
+        emit_cell(3, pw(1, 0), -1, 2);
+        push(kRingPredRemote, 2, 10 + 2, pw(1, kPredStore));        // (p1 + p3) + p2: what the head adds for the launches
+        t.ring_first[17] = (int)desc.size() / 4;
+        emit_cell(5, pw(2, kPredFresh), -1);
+        emit_cell(7, pw(2, 0), -1, 6);
+        push(kRingPredRemote, 6, 10 + 6, pw(2, kPredStore));
+        t.ring_first[18] = (int)desc.size() / 4;
+        emit_cell(2, -1, -1);
+        emit_cell(6, -1, 2);
+        emit_cell(8, pw(3, kPredFresh | kPredStore), 6);
+        t.ring_first[19] = (int)desc.size() / 4;
         put(reinterpret_cast<const float*&>(t.ring_desc), pk.add(desc));
         put(t.pred_head_p, pk.add_split16(headW.data(), 16, 16));
         put(t.pred_head_b, pk.add(headB));
@@ -3215,7 +3313,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         return mz::fail(e == hipErrorOutOfMemory ? MZ_ERR_OOM : MZ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
     if (kind == MZ_NET_TICTACTOE) {
-        const size_t bytes = (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned)) +
+        const size_t bytes = (size_t)kRunMaxRowBlocks * (3 * sizeof(unsigned long long) + sizeof(unsigned)) +
                              4 * sizeof(unsigned long long);
         e = hipMalloc(reinterpret_cast<void**>(&net->run_sync), bytes);
         if (e == hipSuccess) e = hipMemset(net->run_sync, 0, bytes);
@@ -3413,7 +3511,7 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
             ttt_head_kernel<false, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
                                                                out_reward, out_value, out_logits, out_value_raw);
         else
-            ttt_head_kernel<false, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
+            ttt_head_kernel<false, 6><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
                                                                out_reward, out_value, out_logits, out_value_raw);
     } else if (net->kind == MZ_NET_ATARI_SHAPED) {
         atari_kernel<false><<<(batch + 63) / 64, kThreadsW, 0, st>>>(net->atari, batch, hidden_base, parent_block, bs, action,
@@ -3518,7 +3616,7 @@ int mz_debug_run_info(mz_net_t* net, int64_t* out4_host) {
     MZ_HIP(hipStreamSynchronize(net->stream));
     unsigned long long host[4] = {0, 0, 0, 0};
     const char* base = reinterpret_cast<const char*>(net->run_sync) +
-                       (size_t)kRunMaxRowBlocks * (sizeof(unsigned long long) + sizeof(unsigned));
+                       (size_t)kRunMaxRowBlocks * (3 * sizeof(unsigned long long) + sizeof(unsigned));
     MZ_HIP(hipMemcpy(host, base, sizeof(host), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out4_host[i] = (int64_t)host[i];
     return MZ_OK;
@@ -3563,7 +3661,8 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         if (s != MZ_OK) return s;
         RunSync sync;
         sync.arrive = net->run_sync;
-        sync.xcc_mask = reinterpret_cast<unsigned*>(net->run_sync + kRunMaxRowBlocks);
+        sync.cell_flags = net->run_sync + kRunMaxRowBlocks;                          // [row block][2]
+        sync.xcc_mask = reinterpret_cast<unsigned*>(net->run_sync + 3 * kRunMaxRowBlocks);
         sync.stats = reinterpret_cast<unsigned long long*>(sync.xcc_mask + kRunMaxRowBlocks);
         sync.epoch_base = (++net->run_epoch) << kRunEpochShift;
         sync.force_fences = net->run_mode == 1;
@@ -3696,10 +3795,10 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     } else {
         const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
         if (with_select)
-            ttt_head_step_kernel<true, 4><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<true, 6><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                      out_reward, out_value, out_logits, parent_block, action);
         else
-            ttt_head_step_kernel<false, 4><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<false, 6><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                       out_reward, out_value, out_logits, parent_block, action);
     }
     s = launch_status("recurrent inference + tree step");
