@@ -1190,7 +1190,8 @@ __device__ unsigned long long g_run_trace[2048][8];
 #endif
 
 template <bool SPLIT_IO>
-__global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev p, RunSync sync, int nb0, int nsim,
+__global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const PoolDev* pool_image, int T, int* err_flag,
+                                                               RunSync sync, int nb0, int nsim,
                                                                int final_select, float* hidden_base, int* parent_block,
                                                                long block_stride, int* action, float* ppart, float* rpart,
                                                                float* out_reward, float* out_value, float* out_logits,
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
     __shared__ int s_flags[3];                       // [0], [1]: the meetings' flag words, alternating; [2]: fence path
     int job, rb;
     ttt_job_of_block<4>(job, rb);
-    if (rb >= (p.T + 63) / 64) return;               // grid padding: the same for the four workgroups of a row block
+    if (rb >= (T + 63) / 64) return;               // grid padding: the same for the four workgroups of a row block
     // ---- first meeting: agent-scope atomics only (no data crosses it); tells where the four workgroups run
     if (threadIdx.x == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;        // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
     }
     unsigned long long target = sync.epoch_base + 4;
     meet_arrive(sync.arrive + rb, target, false, true, sync.epoch_base, s_flags);
-    bool alive = meet_wait(sync.arrive + rb, target, true, s_flags, p.err_flag);
+    bool alive = meet_wait(sync.arrive + rb, target, true, s_flags, err_flag);
     if (threadIdx.x == 0) {
         const unsigned m = __hip_atomic_load(sync.xcc_mask + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_flags[2] = (sync.force_fences != 0 || __builtin_popcount(m) != 1) ? 1 : 0;
@@ -1231,11 +1232,11 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
         const int nb = nb0 + i;
         const bool traced = trace_parent != nullptr;
         const long long job_t0 = wall_clock64();
-        ttt_ring_body<SPLIT_IO>(w, p.T, hidden_base, parent_block, block_stride, action,
+        ttt_ring_body<SPLIT_IO>(w, T, hidden_base, parent_block, block_stride, action,
                                 hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
-                                traced ? trace_parent + (size_t)i * p.T : nullptr,
-                                traced ? trace_action + (size_t)i * p.T : nullptr, true, sync.cell_flags + 2 * rb,
-                                sync.epoch_base + (unsigned long long)i + 1, p.err_flag);
+                                traced ? trace_parent + (size_t)i * T : nullptr,
+                                traced ? trace_action + (size_t)i * T : nullptr, true, sync.cell_flags + 2 * rb,
+                                sync.epoch_base + (unsigned long long)i + 1, err_flag);
         job_ticks += wall_clock64() - job_t0;
         ++jobs_done;
         MZ_RUN_STAMP(0);
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
         meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags + 1);
         HeadW hw;                                    // requested while the arrival is on its way
         ttt_head_weights(w, hw);
-        alive = meet_wait(sync.arrive + rb, target, fenced, s_flags + 1, p.err_flag);
+        alive = meet_wait(sync.arrive + rb, target, fenced, s_flags + 1, err_flag);
         MZ_RUN_STAMP(1);
         if (!alive) break;
         // ---- head and tree step of 16 games (ttt_head_step_kernel's body): 16 of the row block's 64 games, by the
@@ -1251,6 +1252,19 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
         int tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
         const int ht = tx & (kThreads - 1);
+        // The pool descriptor (65 scalars) is read HERE, every simulation, from its image in device memory (scalar loads
+        // through a pointer the compiler cannot see through, so that it cannot keep them across the jobs): held for the
+        // whole run it pushed the job loop's own scalars out of the register file -- 66 v_readlane a stage.
+        struct PoolWords {
+            int w[sizeof(PoolDev) / sizeof(int)];
+        };
+        typedef const __attribute__((address_space(4))) int* PoolImage;
+        PoolImage image = (PoolImage)reinterpret_cast<const int*>(pool_image);
+        asm volatile("" : "+s"(image));
+        PoolWords words;
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(PoolDev) / sizeof(int)); ++j) words.w[j] = image[j];
+        const PoolDev p = __builtin_bit_cast(PoolDev, words);
         const int tree = tx < kThreads ? hrow0 + ht / G : p.T, gl = ht % G;
         const bool active = tree < p.T && p.n_root[tree] > 0;
         const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
@@ -1275,7 +1289,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, PoolDev
             if (i + 1 < nsim) {                      // the selection of all 64 games, for the next jobs
                 target += 4;
                 meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags);
-                alive = meet_wait(sync.arrive + rb, target, fenced, s_flags, p.err_flag);
+                alive = meet_wait(sync.arrive + rb, target, fenced, s_flags, err_flag);
                 MZ_RUN_STAMP(5);
             }
         }
@@ -3659,6 +3673,8 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         MZ_HIP(hipSetDevice(net->device));
         s = ensure_scratch(net, T);
         if (s != MZ_OK) return s;
+        const PoolDev* image = static_cast<const PoolDev*>(mz_pool_device_image(pool));
+        if (!image) return MZ_ERR_HIP;
         RunSync sync;
         sync.arrive = net->run_sync;
         sync.cell_flags = net->run_sync + kRunMaxRowBlocks;                          // [row block][2]
@@ -3669,12 +3685,12 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         const int grid = 32 * (((T + 63) / 64 + 7) / 8);
         if (net->hidden_split)
             ttt_run_kernel<true><<<grid, kThreadsW, 0, net->stream>>>(
-                net->ttt, pool->dev, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
+                net->ttt, image, T, pool->dev.err_flag, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
                 action, net->ppart, net->rpart, out_reward, out_value, out_logits, (long)out_stride, trace_parent,
                 trace_action);
         else
             ttt_run_kernel<false><<<grid, kThreadsW, 0, net->stream>>>(
-                net->ttt, pool->dev, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
+                net->ttt, image, T, pool->dev.err_flag, sync, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride,
                 action, net->ppart, net->rpart, out_reward, out_value, out_logits, (long)out_stride, trace_parent,
                 trace_action);
         s = launch_status("recurrent inference + tree step, all simulations");

@@ -17,7 +17,14 @@ struct mz_pool {
     long long* counter_scratch = nullptr;
     double* pow_dev = nullptr;  // PoolDev::pow_table
     int pow_next = 0;           // next temperature table to replace once all kPowTables are taken
+    PoolDev* dev_image = nullptr;   // `dev` in device memory, for kernels that read it phase by phase instead of holding
+    PoolDev image_host{};           //   all of it in scalar registers for their whole run (mz_pool_device_image)
+    bool image_valid = false;
 };
+
+// `pool->dev` as the device holds it (re-uploaded on the pool's stream when it has changed since the last call), or
+// nullptr with mz_last_error set.
+const void* mz_pool_device_image(mz_pool* pool);      // (a PoolDev: the type has no linkage across translation units)
 
 // Call-sequence bookkeeping of one expand+backprop (fused with the next select when `with_select`): checks what
 // mz_step / mz_expand_backprop check and returns the block the new nodes take; commit after a successful launch.

@@ -679,6 +679,32 @@ int mz_pool_run_injected(mz_pool* pool, int num_simulations, bool final_select, 
     return MZ_OK;
 }
 
+const void* mz_pool_device_image(mz_pool* pool) {
+    if (hipSetDevice(pool->device) != hipSuccess) return nullptr;
+    if (!pool->dev_image) {
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, sizeof(PoolDev)) != hipSuccess) {
+            mz::fail(MZ_ERR_OOM, "device image of the pool descriptor");
+            return nullptr;
+        }
+        pool->allocations.push_back(ptr);
+        pool->dev_image = static_cast<PoolDev*>(ptr);
+        pool->image_valid = false;
+    }
+    if (!pool->image_valid || memcmp(&pool->image_host, &pool->dev, sizeof(PoolDev)) != 0) {
+        // the previous image may still be read by launches on the stream: the copy is ordered behind them, and its
+        // source is copied to a staging buffer before the call returns (pageable memory)
+        pool->image_host = pool->dev;
+        if (hipMemcpyAsync(pool->dev_image, &pool->image_host, sizeof(PoolDev), hipMemcpyHostToDevice, pool->stream) !=
+            hipSuccess) {
+            mz::fail(MZ_ERR_HIP, "upload of the pool descriptor failed");
+            return nullptr;
+        }
+        pool->image_valid = true;
+    }
+    return pool->dev_image;
+}
+
 int mz_pool_begin_backprop(mz_pool* pool, bool with_select, int* out_new_block) {
     if (!pool->pending) return mz::fail(MZ_ERR_STATE, "expand_backprop without a preceding select");
     const int nb = pool->blocks_in_use;
