@@ -316,6 +316,7 @@ constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3,
 //     raises: the second tap of the producer's next cell) and a first tap's in bits 16.. (1 + the cell whose flag this
 //     stage takes a first look at: the consumer's last own cell, five stages before it needs the answer), 0 = none.
 constexpr int kPredFresh = 1, kPredStore = 2;
+constexpr int kSelTagShift = 20;                     // a selection word: tag << 20 | (parent block + 1) << 8 | action & 0xff
 constexpr long long kRunSpinTicks = 100000000;       // bounded waits of ttt_run_kernel: 1 s of the 100 MHz wall clock
 __device__ __forceinline__ bool ring_gathered(int kind) { return kind <= kRingTapLast || kind == kRingPredRemote; }
 
@@ -346,11 +347,13 @@ __device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[M
 // every workgroup still streams every weight fragment of its stages, so it is the shape of choice only while whole CUs
 // would otherwise have nothing to do).  `pslice`: which 128-float slice of a game's partials this job's sum goes to.
 template <bool SPLIT_IO, int MB = 4>
-__device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const float* in_base, const int* parent_block,
+__device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const float* in_base, const int* parent_block,
                                               long block_stride, const int* action, float* out_hidden, float* ppart,
                                               float* rpart, int rb, int job, int* trace_parent, int* trace_action,
                                               bool coh = false, unsigned long long* cell_flags = nullptr,
-                                              unsigned long long flag_value = 0, int* err_flag = nullptr) {
+                                              unsigned long long flag_value = 0, int* err_flag = nullptr,
+                                              const unsigned long long* sel_words = nullptr, unsigned long long sel_tag = 0,
+                                              long long* waited = nullptr) {
     constexpr int ROWS = 16 * MB, TILE = ROWS * kLdW;
     // descriptor list: the four cell groups (as launches of their own), the nine cells, the four cell groups inside
     // ttt_run_kernel (cell_flags != nullptr: two prediction-conv stages change workgroups)
@@ -362,6 +365,7 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
                                                      // per action; [9*128..]: the cell's 128 reward-head weights;
                                                      // [10*128..]: the dense layer's bias
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
+    __shared__ int sSelOk;                           // ttt_run_kernel: the tagged selections arrived (0: gave up)
     __shared__ float4 sAccP[MB * kThreadsW];          // prediction-conv partial, summed over the job's cells: slot [m][tid]
                                                      // belongs to thread tid alone (registers are the scarce resource)
     // the thread index through a copy the compiler cannot see through: inside ttt_run_kernel's simulation loop nothing
@@ -385,11 +389,42 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
         const int b = row0 + tid;
         long off = -1;
         int a = 0;
+        unsigned long long word = 0;
+        if (MB == 4 && sel_words != nullptr) {
+            // ttt_run_kernel, from a launch's second simulation on: the selections of the row block's 64 games arrive as
+            // words that carry the simulation they are for (kSelTagShift) -- the wavefront looks at them until every one
+            // is this simulation's: the meeting after the tree steps and the load of the selection in one round trip
+            bool ok = b >= B, gave_up = false;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                if (!ok) {
+                    word = __hip_atomic_load(sel_words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (word >> kSelTagShift) == sel_tag;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > kRunSpinTicks) {
+                    gave_up = true;
+                    break;
+                }
+            }
+            if (tid == 0) {
+                sSelOk = gave_up ? 0 : 1;
+                if (gave_up) atomicOr(err_flag, 8);
+                *waited += wall_clock64() - t0;      // (thread 0's: not part of the job's own time, mz_debug_run_info)
+            }
+        }
         if (b < B) {
             // coh: the selection was stored by another workgroup of this launch (ttt_run_kernel)
-            const int pb = !parent_block ? 0 : coh ? load1<true>(parent_block + b) : parent_block[b];
+            int pb;
+            if (MB == 4 && sel_words != nullptr) {
+                pb = (int)((word >> 8) & 0xfffu) - 1;
+                a = (int)(signed char)(word & 0xffu);
+            } else {
+                pb = !parent_block ? 0 : coh ? load1<true>(parent_block + b) : parent_block[b];
+                a = coh ? load1<true>(action + b) : action[b];
+            }
             if (pb >= 0) off = (long)pb * block_stride + (long)b * 1152;
-            a = coh ? load1<true>(action + b) : action[b];
             if (trace_parent != nullptr && job == 0) {      // this simulation's selection as the search made it
                 trace_parent[b] = pb;
                 trace_action[b] = a;
@@ -400,6 +435,7 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
         sAct[tid] = a;
     }
     __syncthreads();
+    if (MB == 4 && sel_words != nullptr && sSelOk == 0) return false;         // (the whole workgroup)
     const float* sptr[MB];
     unsigned svalid = 0;
 #pragma unroll
@@ -669,6 +705,7 @@ __device__ __forceinline__ void ttt_ring_body(const TttDev& w, int B, const floa
         Dn2 = Dn3;
     }
     note_range(vmax, w.range_flag);
+    return true;
 }
 
 // blockIdx -> (job, row block): the jobs of a row block (MB = 4: four cell groups x 64 games; MB = 1: nine cells x 16
@@ -1103,8 +1140,11 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
 // (the next selection of all 64 games is known -> the next jobs gather their parent rows).  What a launch boundary did
 // for these two hand-overs -- make one workgroup's stores visible to the others -- the XCD's L2 does: the four
 // workgroups run on ONE XCD (ttt_job_of_block), a store is in that L2 once `s_waitcnt vmcnt(0)` has returned, and a
-// reader only has to drop its CU's L1 (`buffer_inv sc1`) after it has seen the arrival counter.  The expensive half of
-// an agent-scope release (`buffer_wbl2`: write the whole L2 back) is never needed on that path.
+// reader only has to read past its CU's L1 (`sc1` / `nt` loads: load1 / load4) what it may have cached before.  The
+// expensive half of an agent-scope release (`buffer_wbl2`: write the whole L2 back) is never needed on that path.
+// On that path the second hand-over is not even a meeting: the selections go out as words tagged with the simulation
+// they are for (RunSync::sel_words) and the next job's first wavefront looks at its row block's 64 words until all carry
+// its simulation -- one round trip where the counter, the look at it and the load of the selection were three.
 //   * Where the workgroups run is checked, not assumed: each ORs the bit of its hardware XCC id into a word of its row
 //     block before a first meeting made of agent-scope atomics only; four equal ids -> the L2 path; anything else -> the
 //     same protocol with full agent-scope release / acquire fences around every meeting (correct wherever the workgroups
@@ -1127,8 +1167,12 @@ struct RunSync {
                                     // corners 2 / 6 are complete (the prediction-conv stages that change workgroups)
     unsigned long long* stats;      // [0] row-block runs that took the fence path, [1] row-block runs, [2] 100 MHz wall-clock
                                     // ticks workgroups spent in their jobs, [3] the jobs those ticks are of (measurement)
+    unsigned long long* sel_words;  // [row block][64]: a game's selection for the next simulation, tagged with the
+                                    // launch and that simulation: (epoch << 12 | simulation) << kSelTagShift |
+                                    // (parent block + 1) << 8 | action & 0xff
     unsigned long long epoch_base;  // epoch << kRunEpochShift of this launch
     int force_fences;               // tests: take the agent-scope fence path whatever the placement
+    int tagged_ok;                  // the simulations and blocks of this launch fit a selection word's fields
 };
 
 // A meeting of the four workgroups of a row block, in two halves so that loads which do not depend on the others can be
@@ -1200,6 +1244,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
     __shared__ int s_flags[3];                       // [0], [1]: the meetings' flag words, alternating; [2]: fence path
+    __shared__ int s_sel[2][16];                     // the tree steps' selections (parent block, action) on their way out
     int job, rb;
     ttt_job_of_block<4>(job, rb);
     if (rb >= (T + 63) / 64) return;               // grid padding: the same for the four workgroups of a row block
@@ -1223,6 +1268,12 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
         if (fenced) atomicAdd(sync.stats, 1ull);
     }
     const int hrow0 = rb * 64 + job * 16;
+    // On the L2 path the second meeting of a simulation is no counter: the 16 selections a workgroup has made go out as
+    // tagged words and the next job's first wavefront looks at the 64 of its row block until all are there (ttt_ring_body).
+    // A workgroup that sees them knows that all four are past their heads (a selection is made after its game's partials
+    // were read), so its next job may overwrite the partials; hidden rows were published by the meeting after the jobs.
+    const bool tagged = !fenced && sync.tagged_ok != 0;
+    const unsigned long long sel_epoch = ((sync.epoch_base >> kRunEpochShift) & 0xffffffffull) << 12;
     MZ_RUN_STAMP_DECL;
     long long job_ticks = 0;                         // thread 0: wall-clock ticks inside the jobs (mz_debug_run_info)
     int jobs_done = 0;
@@ -1232,12 +1283,16 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
         const int nb = nb0 + i;
         const bool traced = trace_parent != nullptr;
         const long long job_t0 = wall_clock64();
-        ttt_ring_body<SPLIT_IO>(w, T, hidden_base, parent_block, block_stride, action,
-                                hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
-                                traced ? trace_parent + (size_t)i * T : nullptr,
-                                traced ? trace_action + (size_t)i * T : nullptr, true, sync.cell_flags + 2 * rb,
-                                sync.epoch_base + (unsigned long long)i + 1, err_flag);
-        job_ticks += wall_clock64() - job_t0;
+        long long sel_wait = 0;
+        alive = ttt_ring_body<SPLIT_IO>(w, T, hidden_base, parent_block, block_stride, action,
+                                        hidden_base + (size_t)nb * block_stride, ppart, rpart, rb, job,
+                                        traced ? trace_parent + (size_t)i * T : nullptr,
+                                        traced ? trace_action + (size_t)i * T : nullptr, true, sync.cell_flags + 2 * rb,
+                                        sync.epoch_base + (unsigned long long)i + 1, err_flag,
+                                        tagged && i > 0 ? sync.sel_words + (size_t)rb * 64 : nullptr,
+                                        sel_epoch | (unsigned long long)i, &sel_wait);
+        if (!alive) break;
+        job_ticks += wall_clock64() - job_t0 - sel_wait;
         ++jobs_done;
         MZ_RUN_STAMP(0);
         target += 4;
@@ -1284,12 +1339,30 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             MZ_RUN_STAMP(3);
-            select_tree<G>(p, tree, active, gl, parent_block, action);
-            MZ_RUN_STAMP(4);
-            if (i + 1 < nsim) {                      // the selection of all 64 games, for the next jobs
-                target += 4;
-                meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags);
-                alive = meet_wait(sync.arrive + rb, target, fenced, s_flags, err_flag);
+            if (!tagged) {
+                select_tree<G>(p, tree, active, gl, parent_block, action);
+                MZ_RUN_STAMP(4);
+                if (i + 1 < nsim) {                  // the selection of all 64 games, for the next jobs
+                    target += 4;
+                    meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags);
+                    alive = meet_wait(sync.arrive + rb, target, fenced, s_flags, err_flag);
+                    MZ_RUN_STAMP(5);
+                }
+            } else {
+                select_tree<G>(p, tree, active, gl, &s_sel[0][0] - hrow0, &s_sel[1][0] - hrow0);
+                __syncthreads();
+                MZ_RUN_STAMP(4);
+                if (tx < 16 && hrow0 + tx < p.T) {
+                    const int pa = s_sel[0][tx], ac = s_sel[1][tx];
+                    if (i + 1 < nsim) {
+                        const unsigned long long word = ((sel_epoch | (unsigned long long)(i + 1)) << kSelTagShift) |
+                                                        ((unsigned long long)(unsigned)(pa + 1) << 8) | (unsigned)(ac & 0xff);
+                        __hip_atomic_store(sync.sel_words + hrow0 + tx, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {                         // the launch's last: for the host, or the next launch of the move
+                        parent_block[hrow0 + tx] = pa;
+                        action[hrow0 + tx] = ac;
+                    }
+                }
                 MZ_RUN_STAMP(5);
             }
         }
@@ -2935,8 +3008,8 @@ struct mz_net {
     int scratch_cap = 0;
     int* range_flag = nullptr;     // device word raised by the kernels when a value leaves the split-f16 domain
     float* static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array (mz_infer_recurrent_noalloc)
-    // ttt_run_kernel's meeting words, zeroed once: [kRunMaxRowBlocks] arrival counters, then XCC masks, then two
-    // counters (row-block runs that took the fence path, row-block runs in all)
+    // ttt_run_kernel's meeting words, zeroed once: [kRunMaxRowBlocks] arrival counters, [kRunMaxRowBlocks][2] cell flags,
+    // XCC masks, four counters (mz_debug_run_info), then [kRunMaxRowBlocks][64] tagged selection words (2 MB)
     unsigned long long* run_sync = nullptr;
     unsigned long long run_epoch = 0; // serial number of the last ttt_run_kernel launch
     int job_rows = 0;                 // mz_debug_set_job_rows: 0 = by batch size (ttt_mb), 16 or 64 = that shape always
@@ -3328,7 +3401,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
     }
     if (kind == MZ_NET_TICTACTOE) {
         const size_t bytes = (size_t)kRunMaxRowBlocks * (3 * sizeof(unsigned long long) + sizeof(unsigned)) +
-                             4 * sizeof(unsigned long long);
+                             4 * sizeof(unsigned long long) + (size_t)kRunMaxRowBlocks * 64 * sizeof(unsigned long long);
         e = hipMalloc(reinterpret_cast<void**>(&net->run_sync), bytes);
         if (e == hipSuccess) e = hipMemset(net->run_sync, 0, bytes);
         if (e != hipSuccess) {
@@ -3680,6 +3753,8 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         sync.cell_flags = net->run_sync + kRunMaxRowBlocks;                          // [row block][2]
         sync.xcc_mask = reinterpret_cast<unsigned*>(net->run_sync + 3 * kRunMaxRowBlocks);
         sync.stats = reinterpret_cast<unsigned long long*>(sync.xcc_mask + kRunMaxRowBlocks);
+        sync.sel_words = sync.stats + 4;                                             // [row block][64]
+        sync.tagged_ok = num_simulations < 4096 && nb0 + num_simulations < 4095 ? 1 : 0;
         sync.epoch_base = (++net->run_epoch) << kRunEpochShift;
         sync.force_fences = net->run_mode == 1;
         const int grid = 32 * (((T + 63) / 64 + 7) / 8);
