@@ -1126,9 +1126,10 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     const float* mine = sOut[tid / G];
     backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9], pf);
     if (SELECT) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // a tree's 16 lanes lie inside one wavefront, whose vector memory operations are performed in program order:
+        // compiler ordering is enough (step_kernel, mz_tree.hip)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         select_tree<G>(p, tree, active, gl, out_parent, out_action);
     }
 }
@@ -1335,9 +1336,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
         const float* mine = sOut[ht / G];
         backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9], pf);
         if (i + 1 < nsim || final_select != 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // (a tree's 16 lanes lie inside one wavefront: compiler ordering is enough, as in step_kernel)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             MZ_RUN_STAMP(3);
             if (!tagged) {
                 select_tree<G>(p, tree, active, gl, parent_block, action);
