@@ -55,9 +55,11 @@ extern "C" hipStream_t mz_net_stream_of(const mz_net* net);
 // mz_infer_recurrent_run is one launch for this network and pool (else it loops over mz_infer_recurrent_step)
 extern "C" int mz_net_run_is_one_launch(const mz_net* net, const mz_pool* pool);
 
-// mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL), one launch
+// mz_expand_roots (is_logits = 0) or mz_expand_roots_logits followed by mz_add_root_noise (noise may be NULL) and, when
+// out_parent_block is not NULL, by the first mz_select: one launch
 extern "C" int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits, const int32_t* legal,
-                                     const int32_t* n_legal, const double* noise, double frac);
+                                     const int32_t* n_legal, const double* noise, double frac, int32_t* out_parent_block,
+                                     int32_t* out_action);
 
 // mz_root_stats followed by mz_select_action, one launch
 extern "C" int mz_root_finish(mz_pool_t* pool, int32_t* visits, double* root_value, double* minmax, float* policy,

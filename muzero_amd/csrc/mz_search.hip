@@ -1,7 +1,9 @@
 // One move of T games enqueued from native code: the batched MCTSAgent.make_move (reference agent.py:219-232)
 //   initial_inference -> expand roots -> Dirichlet noise -> N x (select -> recurrent_inference -> expand -> backprop)
 //   -> root statistics -> action sampling
-// as 2N+5 HIP launches (TicTacToe; 5 for CartPole, whose N simulations are one launch) on one stream with no host synchronisation.  Driving the same sequence from Python costs
+// as a handful of HIP launches (initial inference, root expansion + noise + first selection, the N simulations -- one launch
+// where the network has a run kernel, else one or two per simulation --, root statistics + sampling) on one stream with no
+// host synchronisation.  Driving the same sequence from Python costs
 // ~100 us of interpreter time per simulation, more than the kernels themselves at 4096 games.
 #include "mz_common.h"
 #include "mz_pool_internal.h"
@@ -44,8 +46,8 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         ~EndMove() { mz_net_end_move(net); }
     } end_move{net};
     MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
-    MZ_TRY_(mz_expand_roots_noise(pool, io->logits, 1, io->legal, io->n_legal, io->noise, io->noise_frac));
-    MZ_TRY_(mz_select(pool, io->parent_block, io->action));
+    MZ_TRY_(mz_expand_roots_noise(pool, io->logits, 1, io->legal, io->n_legal, io->noise, io->noise_frac, io->parent_block,
+                                  io->action));                      // ... and the first selection
     if (!ev || mz_net_run_is_one_launch(net, pool)) {
         // run_mcts as one call (one launch where the network and pool allow it).  Timing events then bracket the whole
         // run: those of the first simulation that has any are recorded, [0] before it, [1] and [2] after it.
@@ -109,8 +111,7 @@ extern "C" int mz_search_move_injected(mz_pool_t* pool, int32_t num_simulations,
         if (s_ != MZ_OK) return s_; \
     } while (0)
     MZ_TRY_(mz_pool_reset(pool));
-    MZ_TRY_(mz_expand_roots_noise(pool, policy, is_logits, legal, n_legal, noise, noise_frac));
-    MZ_TRY_(mz_select(pool, parent_block, action));
+    MZ_TRY_(mz_expand_roots_noise(pool, policy, is_logits, legal, n_legal, noise, noise_frac, parent_block, action));
     // Timing events around single fused steps ask for the launch per simulation; otherwise the N simulations are ONE
     // launch (run_injected_kernel), bracketed by the first 'before' and the last 'after' event when they are given.
     bool per_step = false;

@@ -286,10 +286,13 @@ __global__ void set_selection_kernel(PoolDev p, int tree, const int* blocks, con
 
 // Root expansion (agent.py:154-160 on the root; positional priors, trap T5).  noise != NULL: add_exploration_noise
 // (agent.py:170-175) in the same pass, the arithmetic of root_noise_kernel on the prior just computed.
-template <int G, bool LOGITS>
+// P > 0: followed by the first selection (select_kernel<G, P>'s, agent.py:177-190) of the same trees -- a tree's group
+// lies inside one wavefront, which reads back what it has just written (step_kernel) -- one launch less per move.
+template <int G, bool LOGITS, int P = 0>
 __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, const float* pol, const int* legal,
                                                                      const int* n_legal, const double* noise,
-                                                                     double frac) {
+                                                                     double frac, int* out_parent = nullptr,
+                                                                     int* out_action = nullptr) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
     const int tree = gid / G, gl = gid % G;
     const int A = p.A;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         total = numpy_sum_f32<G>(p, stage, stage + A, (in && n > 0) ? gl : 1 << 30);
     }
-    if (!in) return;
+    if (!in) return;                       // (whole groups: a tree's lanes leave together)
     Slot* slots = f_slots(p, r);
     for (int k = gl; k < n; k += G) {
         int a = legal ? legal[(size_t)tree * A + k] : k;
@@ -348,6 +351,11 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
         p.mm_min[tree] = std::numeric_limits<double>::infinity();    // utils.py:60-61
         p.mm_max[tree] = -std::numeric_limits<double>::infinity();
         p.path_len[tree] = 0;
+    }
+    if constexpr (P > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        select_tree<G, P>(p, tree, n > 0, gl, out_parent, out_action, nullptr);
     }
 }
 
@@ -596,11 +604,31 @@ int check_launch(const char* what) {
 }
 
 int expand_roots_impl(mz_pool* pool, const float* pol, const int32_t* legal, const int32_t* n_legal, bool logits,
-                      const double* noise = nullptr, double frac = 0.0) {
+                      const double* noise = nullptr, double frac = 0.0, int32_t* out_parent = nullptr,
+                      int32_t* out_action = nullptr) {
     MZ_REQUIRE(pool != nullptr, "pool is NULL");
     MZ_REQUIRE(pol != nullptr, "priors/logits is NULL");
     MZ_HIP(hipSetDevice(pool->device));
     const int grid = grid_for(pool);
+    if (out_parent != nullptr) {             // with the first selection
+        MZ_REQUIRE(out_action != nullptr, "out_action is NULL");
+        if (pool->dev.N < 1) return mz::fail(MZ_ERR_STATE, "pool is full: it holds no simulation");
+        dispatch_group_passes(pool->G, pool->P, [&](auto g, auto pp) {
+            constexpr int G = decltype(g)::value;
+            constexpr int P = decltype(pp)::value;
+            if (logits)
+                expand_roots_kernel<G, true, P><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal, noise,
+                                                                                          frac, out_parent, out_action);
+            else
+                expand_roots_kernel<G, false, P><<<grid, kBlockThreads, 0, pool->stream>>>(pool->dev, pol, legal, n_legal, noise,
+                                                                                           frac, out_parent, out_action);
+        });
+        MZ_TRY(check_launch("expand_roots_kernel + select"));
+        pool->blocks_in_use = 1;
+        pool->select_launches++;
+        pool->pending = true;
+        return MZ_OK;
+    }
     dispatch_group(pool->G, [&](auto g) {
         constexpr int G = decltype(g)::value;
         if (logits)
@@ -906,11 +934,13 @@ int mz_expand_roots_logits(mz_pool_t* pool, const float* logits, const int32_t* 
     return expand_roots_impl(pool, logits, legal, n_legal, true);
 }
 
-// Internal to the library (mz_pool_internal.h): mz_expand_roots[_logits] followed by mz_add_root_noise, as one launch.
+// Internal to the library (mz_pool_internal.h): mz_expand_roots[_logits] followed by mz_add_root_noise -- and, when
+// out_parent_block is given, by the first mz_select -- as one launch.
 __attribute__((visibility("hidden"))) int mz_expand_roots_noise(mz_pool_t* pool, const float* pol, int32_t is_logits,
                                                                 const int32_t* legal, const int32_t* n_legal,
-                                                                const double* noise, double frac) {
-    return expand_roots_impl(pool, pol, legal, n_legal, is_logits != 0, noise, frac);
+                                                                const double* noise, double frac,
+                                                                int32_t* out_parent_block, int32_t* out_action) {
+    return expand_roots_impl(pool, pol, legal, n_legal, is_logits != 0, noise, frac, out_parent_block, out_action);
 }
 
 int mz_add_root_noise(mz_pool_t* pool, const double* noise, double frac) {
