@@ -313,8 +313,9 @@ constexpr int kRingTapFirst = 0, kRingTap = 1, kRingTapLast = 2, kRingDense = 3,
 //     rows just written (the producer raises a per-cell flag once its stores are complete, the consumer looks at the flag
 //     before it requests the rows), everything else is a prediction-conv stage;
 //   * a tap's .x carries in bits 8..15 (1 + the cell whose hidden' rows are complete by then and whose flag this stage
-//     raises: the second tap of the producer's next cell) and a first tap's in bits 16.. (1 + the cell whose flag this
-//     stage takes a first look at: the consumer's last own cell, five stages before it needs the answer), 0 = none.
+//     raises: the second tap of the producer's next cell), 0 = none.  (A first look at the flag some stages before the
+//     consumer needs the answer was measured and dropped: an agent-scope load at the head of a stage's in-order queue
+//     of weight loads cost 1 % of the move; the one look where the answer is needed almost always finds the flag up.)
 constexpr int kPredFresh = 1, kPredStore = 2;
 constexpr int kSelTagShift = 20;                     // a selection word: tag << 20 | (parent block + 1) << 8 | action & 0xff
 constexpr long long kRunSpinTicks = 100000000;       // bounded waits of ttt_run_kernel: 1 s of the 100 MHz wall clock
@@ -464,7 +465,6 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
     for (int m = 0; m < MB; ++m) lact[m] = sAct[16 * m + n16];
     f32x4 acc[MB], acx[MB];
     float4 af[2][MB][2];                              // activation fragments: ring over k-steps, carried across stages
-    unsigned long long flag_seen = 0;                // thread 0: the flag of the remote cell as requested ahead of its use
     int cur = 0, nxt = 1;                            // ring positions of this stage's and the next stage's tile
     Desc Dc = D0, Dn = desc[1], Dn2 = desc[2];
     MZ_TRACE_DECL;
@@ -491,8 +491,6 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
         const bool load2 = d + 2 < d1 && ring_gathered(Dn2.x & 0xff);   // request the tile of the stage after the next
         const bool remote2 = (Dn2.x & 0xff) == kRingPredRemote;  // ... from this simulation's hidden' rows of cell Dn2.y
         const int src2 = remote2 ? Dn2.y * 128 : Dn2.w * 128;
-        if (MB == 4 && cell_flags != nullptr && kind == kRingTapFirst && (Dc.x >> 16) != 0 && tid == 0)
-            flag_seen = __hip_atomic_load(cell_flags + ((Dc.x >> 16) - 1 == 2 ? 0 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (MB == 4 && remote2) {
             // the remote prediction-conv stage is a job's last gathered stage: from here on the gather pointers are the
             // rows row0 + r of THIS simulation's block, as their producer stored them (outside the MFMA section, which
@@ -606,8 +604,8 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
                 // have raised the cell's flag (it did so a dozen stages ago unless something is badly out of step)
                 const unsigned long long* flag = cell_flags + (Dn3.y == 2 ? 0 : 1);
                 const long long t0 = wall_clock64();
-                while ((long long)(flag_seen - flag_value) < 0) {        // (as a rule the early look has seen it already)
-                    flag_seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const unsigned long long flag_seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((long long)(flag_seen - flag_value) >= 0) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > kRunSpinTicks) {
@@ -3164,8 +3162,8 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         // their stages for the ring kernel: (kind, cell, weight matrix, source cell); matrices 0..8 = conv taps,
         // 9 = Dense, 10 + c = prediction conv of cell c (consecutive in the packed buffer, checked below)
         // one cell: its valid taps, Dense, and (pred_w >= 0) its prediction-conv stage with .w = pred_w; `signal` = the cell
-        // whose flag the second tap raises, `look` = the cell whose flag the first tap takes an early look at (-1: none)
-        auto emit_cell = [&](int c, int pred_w, int signal, int look = -1) {
+        // whose flag the second tap raises (-1: none)
+        auto emit_cell = [&](int c, int pred_w, int signal) {
             int valid[9], nv = 0;
             for (int tp = 0; tp < 9; ++tp) {
                 const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
@@ -3173,7 +3171,7 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
             }
             for (int i = 0; i < nv; ++i) {
                 const int tp = valid[i];
-                push(i == 0 ? (kRingTapFirst | ((look + 1) << 16)) : i == nv - 1 ? kRingTapLast : (kRingTap | (i == 1 ? (signal + 1) << 8 : 0)), c, tp,
+                push(i == 0 ? kRingTapFirst : i == nv - 1 ? kRingTapLast : (kRingTap | (i == 1 ? (signal + 1) << 8 : 0)), c, tp,
                      (c / 3 + tp / 3 - 1) * 3 + (c % 3 + tp % 3 - 1));
             }
             push(kRingDense, c, 9, 0);
@@ -3211,11 +3209,11 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         emit_cell(0, pw(0, kPredStore), -1);
         t.ring_first[16] = (int)desc.size() / 4;
         emit_cell(1, pw(1, kPredFresh), -1);
-        emit_cell(3, pw(1, 0), -1, 2);
+        emit_cell(3, pw(1, 0), -1);
         push(kRingPredRemote, 2, 10 + 2, pw(1, kPredStore));        // (p1 + p3) + p2: what the head adds for the launches
         t.ring_first[17] = (int)desc.size() / 4;
         emit_cell(5, pw(2, kPredFresh), -1);
-        emit_cell(7, pw(2, 0), -1, 6);
+        emit_cell(7, pw(2, 0), -1);
         push(kRingPredRemote, 6, 10 + 6, pw(2, kPredStore));
         t.ring_first[18] = (int)desc.size() / 4;
         emit_cell(2, -1, -1);
