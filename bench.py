@@ -270,7 +270,7 @@ class NetworkMove:
             # 128, policy 9*128) -- SURVEY.md 8(d)'s 2.35 MFLOP per evaluation, multiply-adds x2 -- and the tree steps
             self.dominant = 'ttt_run_kernel'
             self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128 + 128 * 128 + 128 + 9 * 128)
-            if run_mode == 2 or (job_rows or (16 if wl['T'] <= 1792 else 64)) == 16:
+            if run_mode == 2 or (job_rows or (64 if wl['T'] > 2560 else 32)) != 64:
                 # a launch per simulation (A/B runs; batches of 16-game jobs): the job kernel and its terms alone
                 self.dominant = 'ttt_ring_kernel'
                 self.flops_per_eval = 2 * (49 * 137 * 128 + 9 * 128 * 128 + 1152 + 9 * 128 * 128)
@@ -536,7 +536,7 @@ def main():
                          'simulation (Network.set_run_mode)')
     ap.add_argument('--lanes-per-tree', type=int, default=0,
                     help='tree-only A/B measurements: lanes of a wavefront per tree (TreePool lanes_per_tree; 0 = its choice)')
-    ap.add_argument('--job-rows', type=int, default=0, choices=[0, 16, 64],
+    ap.add_argument('--job-rows', type=int, default=0, choices=[0, 16, 32, 64],
                     help='TicTacToe A/B measurements: games per workgroup of the job kernel (Network.set_job_rows)')
     ap.add_argument('--sync-every', type=int, default=0, help='synchronise the host every n timed steps (0 = never)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],

@@ -224,9 +224,10 @@ int mz_net_set_mid_event(mz_net_t* net, void* hip_event);
  * number of jobs (workgroups x simulations) those ticks belong to.  Synchronises. */
 int mz_debug_set_run_mode(mz_net_t* net, int32_t mode);
 /* Test / measurement switch of the TicTacToe job kernel's shape: rows = 0 (default) chooses by batch size -- 16 games x one
- * board cell per workgroup up to 1792 games, 64 games x a group of cells beyond --, 16 or 64 force that shape.  The two
- * shapes sum the prediction conv's per-cell terms in different orders: results agree to float rounding (both are held to
- * 1e-5 of the fp64 oracle), not bit for bit. */
+ * board cell per workgroup up to 768 games, 32 games x one cell up to 2560, 64 games x a group of cells beyond --, 16, 32
+ * or 64 force that shape.  The single-cell shapes give bit-identical results; the 64-game shape sums the prediction
+ * conv's per-cell terms in a different order: it agrees with them to float rounding (all are held to 1e-5 of the fp64
+ * oracle), not bit for bit. */
 int mz_debug_set_job_rows(mz_net_t* net, int32_t rows);
 int mz_debug_run_info(mz_net_t* net, int64_t* out4_host);
 

@@ -343,10 +343,10 @@ __device__ __forceinline__ void ring_commit(_Float16* buf, const float4 (&stg)[M
 // The job of workgroup (row block rb, job) -- the whole of ttt_ring_kernel, and one phase of a simulation in
 // ttt_run_kernel (whose pointers change meaning between two calls: no __restrict__ here).  Ends with every wave past
 // its last LDS access of the job but NOT with a barrier.
-// MB = 16-row blocks per workgroup: 4 (64 games x a group of cells, the shape for large batches) or 1 (16 games x ONE
-// cell: nine workgroups per 16 games, for batches that would leave most of the chip idle at 64 games a workgroup --
-// every workgroup still streams every weight fragment of its stages, so it is the shape of choice only while whole CUs
-// would otherwise have nothing to do).  `pslice`: which 128-float slice of a game's partials this job's sum goes to.
+// MB = 16-row blocks per workgroup: 4 (64 games x a group of cells, the shape for large batches), or 1 / 2 (16 / 32 games
+// x ONE cell: nine workgroups per 16 / 32 games, for batches that would leave most of the chip idle at 64 games a
+// workgroup -- every workgroup still streams every weight fragment of its stages, so they are the shapes of choice only
+// while whole CUs would otherwise have nothing to do; ttt_mb).  `pslice`: which 128-float slice of a game's partials this job's sum goes to.
 template <bool SPLIT_IO, int MB = 4>
 __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const float* in_base, const int* parent_block,
                                               long block_stride, const int* action, float* out_hidden, float* ppart,
@@ -358,7 +358,7 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
     constexpr int ROWS = 16 * MB, TILE = ROWS * kLdW;
     // descriptor list: the four cell groups (as launches of their own), the nine cells, the four cell groups inside
     // ttt_run_kernel (cell_flags != nullptr: two prediction-conv stages change workgroups)
-    const int djob = MB == 1 ? 5 + job : cell_flags != nullptr ? 15 + job : job;
+    const int djob = MB != 4 ? 5 + job : cell_flags != nullptr ? 15 + job : job;
     __shared__ __attribute__((aligned(16))) _Float16 sRing[3 * TILE];
     __shared__ long sRowOff[ROWS];
     __shared__ int sAct[ROWS];
@@ -484,7 +484,11 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
                                                                 // whole stage to arrive in
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
         const float4* wnext = wlane + (size_t)(has_next ? Dn.z : Dc.z) * 4096;
-        const bool primed = d > 0 && ring_gathered(kind);        // af[0] holds this stage's first fragments already
+        // af[0] holds this stage's first fragments already: requested under the previous stage's last MFMAs (a gathered
+        // tile) or, in the 16-game jobs, right behind the barrier that ended its epilogue (a tile written by that epilogue:
+        // +0.5 % at 512 games; in the 64-game jobs the 32 registers held across the epilogue spill: 87.3 vs 90.7 M)
+        constexpr bool kPrimeCold = MB == 1;
+        const bool primed = d > 0 && (kPrimeCold || ring_gathered(kind));
         const bool commit = has_next && ring_gathered(Dn.x & 0xff);     // the next stage's tile is gathered: it is committed
                                                                  // after k-step 1, a barrier follows, k-step 3 reads its
                                                                  // first fragments
@@ -616,6 +620,14 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
             }
             __syncthreads();
             MZ_TRACE_NW(4);                          // barrier
+            if (kPrimeCold) {   // the Dense stage's first fragments, requested before the loop's bookkeeping and set-up
+                const _Float16* np = sRing + nxt * TILE + n16 * kLdW + 8 * g;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    af[0][m][0] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW);
+                    af[0][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
+                }
+            }
         } else if (kind == kRingDense) {     // Dense 128 -> 128 relu = hidden'[cell] (games/tictactoe.py:191)
             fold4(acc, acx);
             float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;       // uniform
@@ -656,6 +668,15 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
             MZ_TRACE_NW(3);
             __syncthreads();
             MZ_TRACE_NW(4);
+            if (kPrimeCold && !commit) {   // the prediction-conv stage's first fragments: requested ahead of the copy-out
+                                           // below, whose LDS reads and stores then issue inside their latency
+                const _Float16* np = sH + n16 * kLdW + 8 * g;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    af[0][m][0] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW);
+                    af[0][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
+                }
+            }
             if (SPLIT_IO) {                        // the tile is the row image the workspace wants: 16 bytes a thread
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
@@ -3538,12 +3559,20 @@ int mz_infer_initial(mz_net_t* net, int32_t batch, const float* observation, flo
 }
 
 // The TicTacToe job kernel, reading and writing f32 hidden rows or, inside a native move, their split images.
-// Batches up to this many games run as 16-game single-cell jobs (nine workgroups per 16 games) and a head that sums nine
-// partials; larger ones as 64-game jobs over four cell groups.  Where 64-game jobs would occupy fewer than half of the
-// CUs the smaller jobs win although every workgroup streams its stages' weights again (measured: DESIGN.md section 3).
-constexpr int kTttSmallBatch = 1792;
+// Three shapes by batch size (16-row blocks per workgroup): up to kTttSmallBatch games 16 games x ONE cell (nine
+// workgroups per 16 games, a head that sums nine partials), up to kTttMidBatch games 32 games x one cell (half the
+// weight bytes per game through the L2, which is what bounds the single-cell jobs once most CUs have one), beyond
+// that 64 games x a group of cells -- the shape of the one-launch move.  Measured (simulations/s at 25 simulations a move,
+// 16 / 32 / 64 games): 512 games 22.0 / 20.0 / 11.4 M, 768: 29.5 / 29.2 / 18.1, 1024: 34.9 / 36.7 / 22.5, 1536: 41.4 /
+// 46.9 / 35.9, 2048: 47.1 / 54.4 / 44.0, 2560: 50.8 / 59.2 / 58.6, 3072: 53.2 / 64.5 / 69.8, 4096: 56.7 / 70.5 / 90.4.
+constexpr int kTttSmallBatch = 768, kTttMidBatch = 2560;
 static int ttt_mb(const mz_net* net, int batch) {
-    return net->job_rows == 16 ? 1 : net->job_rows == 64 ? 4 : batch <= kTttSmallBatch ? 1 : 4;
+    return net->job_rows == 16   ? 1
+           : net->job_rows == 32 ? 2
+           : net->job_rows == 64 ? 4
+           : batch <= kTttSmallBatch ? 1
+           : batch <= kTttMidBatch   ? 2
+                                     : 4;
 }
 
 static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, const int* parent_block, long bs,
@@ -3556,6 +3585,13 @@ static void launch_job_kernel(mz_net* net, int batch, const float* hidden_base, 
                                                                  out_hidden, ppart, rpart);
         else
             ttt_ring_kernel<false, 1><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                  out_hidden, ppart, rpart);
+    } else if (mb == 2) {
+        if (split_hidden)
+            ttt_ring_kernel<true, 2><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
+                                                                 out_hidden, ppart, rpart);
+        else
+            ttt_ring_kernel<false, 2><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
                                                                   out_hidden, ppart, rpart);
     } else if (split_hidden) {
         ttt_ring_kernel<true, 4><<<grid, kThreadsW, 0, st>>>(net->ttt, batch, hidden_base, parent_block, bs, action,
@@ -3593,7 +3629,7 @@ static int infer_recurrent(mz_net_t* net, int32_t batch, const float* hidden_bas
         launch_job_kernel(net, batch, hidden_base, parent_block, bs, action, out_hidden, split_hidden, ppart, rpart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
         const int nhb = (batch + 15) / 16;
-        if (ttt_mb(net, batch) == 1)
+        if (ttt_mb(net, batch) != 4)
             ttt_head_kernel<false, 9><<<nhb, kThreads, 0, st>>>(net->ttt, batch, parent_block, ppart, rpart,
                                                                out_reward, out_value, out_logits, out_value_raw);
         else
@@ -3689,7 +3725,7 @@ int mz_debug_set_run_mode(mz_net_t* net, int32_t mode) {
 
 int mz_debug_set_job_rows(mz_net_t* net, int32_t rows) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
-    MZ_REQUIRE(rows == 0 || rows == 16 || rows == 64, "job rows must be 0, 16 or 64 (got %d)", rows);
+    MZ_REQUIRE(rows == 0 || rows == 16 || rows == 32 || rows == 64, "job rows must be 0, 16, 32 or 64 (got %d)", rows);
     net->job_rows = rows;
     return MZ_OK;
 }
@@ -3874,7 +3910,7 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     launch_job_kernel(net, batch, hidden_base, parent_block, (long)block_stride, action, out_hidden, net->hidden_split,
                       net->ppart, net->rpart);
     if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-    if (ttt_mb(net, batch) == 1) {
+    if (ttt_mb(net, batch) != 4) {
         const int grid = (batch + 15) / 16;
         if (with_select)
             ttt_head_step_kernel<true, 9><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,

@@ -27,7 +27,7 @@ def _decode_hidden(game, hidden):
 
 # replayed: how many live trees go through the C oracle (None = every one of them; the Atari shape reads 50 records of
 # a tree back one call at a time, so it keeps a sample)
-@pytest.mark.parametrize('game,T,N,replayed', [('tictactoe', 4096, 25, None), ('tictactoe', 512, 25, None),
+@pytest.mark.parametrize('game,T,N,replayed', [('tictactoe', 4096, 25, None), ('tictactoe', 512, 25, None), ('tictactoe', 2048, 25, None),
                                                ('cartpole', 1024, 50, None), ('atari', 16384, 50, 1024)])
 def test_native_move_full_size_against_the_oracles(game, T, N, replayed):
     import torch

@@ -693,7 +693,7 @@ def test_tictactoe_one_launch_move_equals_the_launch_per_simulation(T):
     N, A = 25, 9
     config = tictactoe.make_config(num_simulations=N)
     net = config.network_config.network_class(config, seed=11)
-    net.set_job_rows(64)          # the one-launch move is the 64-game jobs' (by default only batches > 1792 take them)
+    net.set_job_rows(64)          # the one-launch move is the 64-game jobs' (by default only batches > 2560 take them)
     rng = np.random.default_rng(T)
     obs = rng.integers(0, 2, size=(T, 27)).astype(np.float32)
     n_legal = rng.integers(0, A + 1, size=T).astype(np.int32)
@@ -739,6 +739,48 @@ def test_tictactoe_one_launch_move_equals_the_launch_per_simulation(T):
     assert results[2][0][0][live].sum() == live.sum() * N
     # on this part the four workgroups of a row block are dealt to one XCD: the L2 path is the one that ran
     assert results['fenced_in_default_mode'] == 0
+
+
+def test_tictactoe_single_cell_job_shapes_are_bit_identical():
+    """The 16-game and the 32-game single-cell jobs (ttt_ring_kernel<., 1> / <., 2>, chosen by batch size) compute every row
+    with the same instructions in the same order and hand the head the same nine per-cell slices: a whole move -- outputs,
+    traces, hidden workspace -- must agree bit for bit.  A batch that is a multiple of neither 16 nor 32, ragged legal
+    lists, finished games."""
+    import torch
+    from muzero_amd.games import tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    T, N, A = 210, 25, 9
+    config = tictactoe.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, seed=5)
+    rng = np.random.default_rng(77)
+    obs = rng.integers(0, 2, size=(T, 27)).astype(np.float32)
+    n_legal = rng.integers(0, A + 1, size=T).astype(np.int32)
+    n_legal[:4] = A
+    legal = np.zeros((T, A), np.int32)
+    noise = np.zeros((T, A))
+    for t in range(T):
+        legal[t, :n_legal[t]] = np.sort(rng.permutation(A)[:n_legal[t]])
+        if n_legal[t]:
+            noise[t, :n_legal[t]] = rng.dirichlet([1.0] * int(n_legal[t]))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = (dev(obs), dev(noise), dev(rng.random(T)), dev(np.ones(T)), dev(legal), dev(n_legal))
+    results = {}
+    for rows in (16, 32):
+        net.set_job_rows(rows)
+        search = LockstepSearch(config, net, num_trees=T)
+        search.hidden.zero_()
+        tr = {}
+        out = [x.cpu().numpy().copy() for x in search.run_native(*args, trace=tr)]
+        search.pool.counters()
+        results[rows] = (out, {k: v.cpu().numpy().copy() for k, v in tr.items()}, search.hidden.cpu().numpy().copy())
+    net.set_job_rows(0)
+    live = n_legal > 0
+    for a, b in zip(results[16][0], results[32][0]):
+        np.testing.assert_array_equal(a, b)
+    for k in results[16][1]:
+        np.testing.assert_array_equal(results[16][1][k], results[32][1][k], err_msg=f'trace {k}')
+    np.testing.assert_array_equal(results[16][2][:, live].view(np.uint32), results[32][2][:, live].view(np.uint32))
+    assert results[16][0][0][live].sum() == live.sum() * N
 
 
 @pytest.mark.parametrize('name', ['ttt_legal_s2', 'atari_s9', 'asym_bounds_s15'])
