@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlockThreads) MZ_WAVES(P) void select_kernel(PoolD
 template <int G, int PB>
 struct BackupInputs {
     bool active;
+    int n_root;
     BackupPrefetchT<PB> pf;
     float reward, value;
     const float* pol_row;
@@ -83,6 +84,7 @@ __device__ __forceinline__ BackupInputs<G, PB> backup_inputs(const PoolDev& p, i
     b.value = value[tc];
     b.pol_row = pol + (size_t)tc * p.A;
     b.active = in && n_root > 0;
+    b.n_root = n_root;
     if (!b.active) {
         b.pf.len = 0;
         b.reward = 0.f;
@@ -214,6 +216,11 @@ __global__ __launch_bounds__(kBlockThreads) void run_injected_kernel(PoolDev p, 
         }
         const BackupInputs<G, PB> b = backup_inputs<G, PB>(p, tree, gl, pol_s, reward + (size_t)s * rv_stride,
                                                            value + (size_t)s * rv_stride);
+        // the root's slots as they are before this backup, for the select that follows it (mz_tree_dev.h, RootPre)
+        const bool with_select = s + 1 < nsim || final_select != 0;
+        RootPre<P> pre = root_prefetch<G, P>(p, tree, tree < p.T && with_select, gl);
+        pre.n_root = b.n_root;
+        RootFwd fw;
         const float* pol_row = b.pol_row;
         if (p.A <= TreeLds<G>::kMaxA) {
 #pragma unroll
@@ -224,10 +231,10 @@ __global__ __launch_bounds__(kBlockThreads) void run_injected_kernel(PoolDev p, 
             pol_row = s_pol_row;
             __builtin_amdgcn_wave_barrier();                     // the row is this wavefront's own: DS order is enough
         }
-        backprop_tree<G, LOGITS, PB>(p, tree, b.active, gl, nb0 + s, pol_row, b.reward, b.value, b.pf, lds_row);
+        backprop_tree<G, LOGITS, PB, true>(p, tree, b.active, gl, nb0 + s, pol_row, b.reward, b.value, b.pf, lds_row, &fw);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (s + 1 < nsim || final_select != 0) select_tree<G, P>(p, tree, b.active, gl, out_parent, out_action, lds_log);
+        if (with_select) select_tree<G, P, true>(p, tree, b.active, gl, out_parent, out_action, lds_log, &pre, &fw);
         __builtin_amdgcn_wave_barrier();
     }
 }

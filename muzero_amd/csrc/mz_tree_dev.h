@@ -231,6 +231,46 @@ __device__ __forceinline__ LdsLog stage_log_table(const PoolDev& p, double* s_lo
     return (LdsLog)s_log;
 }
 
+// ---- The root level without a round trip (run_injected_kernel).  A simulation's backup and the select that follows it
+// belong to one group: what the select reads of the root -- its children's slots, their priors, the root's count and
+// the tree's value bounds -- is what was there BEFORE the backup, except for the one child on the path and the
+// statistics the backup itself computes.  So the root's slots are requested together with the backup's inputs
+// (root_prefetch: they land while the new node is being expanded), the backup hands over what it changed (RootFwd),
+// and the select's first level scores from registers.  Same values, same order, same result.
+template <int PP>
+struct RootPre {                   // this lane's slots j * G + gl, j < PP, of the root as they were before the backup
+    int c[PP], ch[PP], act[PP];
+    double q[PP], pr[PP];
+    int n_root;
+};
+struct RootFwd {                   // what the backup changed (every lane of the group holds the same values)
+    bool ok;                       // false: the backup took the long-path route, the select reads the root itself
+    int k0, c0, ch0;               // the root's child on the path: slot, new count, new child word (ch_set)
+    bool ch_set;
+    double q0;                     // its new exploitation term as stored in the slot
+    int root_count;                // the root's new visit count
+    double mn, mx;                 // the tree's value bounds after the backup (pools without known bounds)
+};
+// (slots past the root's listed children exist in the record and are never scored: no need to know n_root to ask)
+template <int G, int PP>
+__device__ __forceinline__ RootPre<PP> root_prefetch(const PoolDev& p, int tree, bool in, int gl) {
+    RootPre<PP> r;
+    r.n_root = 0;                                // the caller's, once it has arrived
+    const int upto = min(p.A, PP * G);
+    const Slot* slots = f_slots(p, rec(p, in ? tree : 0, 0));
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int k = max(min(j * G + gl, upto - 1), 0);
+        const Slot s = slots[k];
+        r.c[j] = s.count;
+        r.q[j] = s.q;
+        r.ch[j] = s.child_hi;
+        r.act[j] = s.act;
+        r.pr[j] = p.root_prior[(size_t)(in ? tree : 0) * p.A + k];
+    }
+    return r;
+}
+
 struct SelectNorm {                // MinMaxStats.normalize as this select call sees it (utils.py:68-76)
     double na, nd, dflt;           // (x - na) / nd; dflt: the normalised default value of an unvisited child
     bool renorm;                   // q holds raw reward + discount*value (bounds unknown and max != min)
@@ -244,9 +284,10 @@ struct LevelWinner {
 // One node: scores slots [0, target) -- growing the prefix while its last slot ties with the best -- with PP slots per
 // lane in flight, and returns the winner in every lane of the group.  Wave-wide: lanes of groups that are `done`
 // come along idle.
-template <int G, int PP, bool ROOT>
+template <int G, int PP, bool ROOT, bool FWD = false>
 __device__ __forceinline__ LevelWinner scan_level(const PoolDev& p, int tree, int gl, bool done, const Slot* slots,
-                                                  int np_, LdsLog lds_log, const SelectNorm& nm, int target) {
+                                                  int np_, LdsLog lds_log, const SelectNorm& nm, int target,
+                                                  const RootPre<PP>* pre = nullptr, const RootFwd* fw = nullptr) {
     const int A = p.A;
     const int gbase = (int)(threadIdx.x & 63u) & ~(G - 1);   // first lane of this group in the wavefront
     const unsigned long long gbits = G == 64 ? ~0ull : ((1ull << G) - 1ull);
@@ -273,15 +314,28 @@ __device__ __forceinline__ LevelWinner scan_level(const PoolDev& p, int tree, in
                 if (lds_log != nullptr) lt = lds_log[np_];
                 else lt = p.log_table[np_];
             }
+            if (FWD && round == 0 && fw->ok) {
+                // the root as prefetched before the backup, with the backup's one change
 #pragma unroll
-            for (int j = 0; j < PP; ++j) {
-                const int k = min(base + j * G + gl, upto - 1);
-                const Slot s = slots[k];
-                c[j] = s.count;
-                q[j] = s.q;
-                ch[j] = s.child_hi;
-                act[j] = s.act;
-                pr[j] = ROOT ? p.root_prior[(size_t)tree * A + k] : (double)s.prior;
+                for (int j = 0; j < PP; ++j) {
+                    const bool hit = j * G + gl == fw->k0;
+                    c[j] = hit ? fw->c0 : pre->c[j];
+                    q[j] = hit ? fw->q0 : pre->q[j];
+                    ch[j] = hit && fw->ch_set ? fw->ch0 : pre->ch[j];
+                    act[j] = pre->act[j];
+                    pr[j] = pre->pr[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PP; ++j) {
+                    const int k = min(base + j * G + gl, upto - 1);
+                    const Slot s = slots[k];
+                    c[j] = s.count;
+                    q[j] = s.q;
+                    ch[j] = s.child_hi;
+                    act[j] = s.act;
+                    pr[j] = ROOT ? p.root_prior[(size_t)tree * A + k] : (double)s.prior;
+                }
             }
             pin(lt);
 #pragma unroll
@@ -347,9 +401,9 @@ __device__ __forceinline__ LevelWinner scan_level(const PoolDev& p, int tree, in
 }
 
 // lds_log: the pool's log table staged in LDS (see stage_log_table), or nullptr to read it from global memory.
-template <int G, int P = 1>
+template <int G, int P = 1, bool FWD = false>
 __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int* out_parent, int* out_action,
-                            LdsLog lds_log = nullptr) {
+                            LdsLog lds_log = nullptr, const RootPre<P>* pre = nullptr, const RootFwd* fw = nullptr) {
     const int A = p.A;
     int e = 0, np_ = 0, target = 0, depth = 0, hi = 0;
     int* hi_home = nullptr;        // where the current node's (hi, block) word lives: its parent's slot
@@ -359,7 +413,15 @@ __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int
     SelectNorm nm;
     nm.na = p.kmin;
     nm.nd = p.kmax - p.kmin;
-    if (active) {
+    if (FWD && active && fw->ok) {               // (fw->ok is the same in every lane of the wavefront)
+        np_ = fw->root_count;
+        target = pre->n_root;
+        if (!p.has_bounds) {
+            ident = (fw->mx == fw->mn);
+            nm.na = fw->mn;
+            nm.nd = fw->mx - fw->mn;
+        }
+    } else if (active) {
         np_ = p.root_count[tree];
         target = p.n_root[tree];
         if (!p.has_bounds) {
@@ -386,7 +448,7 @@ __device__ void select_tree(const PoolDev& p, int tree, bool active, int gl, int
         if (!done) slots = f_slots(p, rec(p, tree, e));
         // the root: every listed child, P per lane; below it a prefix (see above), one slot per lane and round --
         // unless the pool keeps its nodes unsorted, whose every child is read, again P per lane
-        const LevelWinner w = root           ? scan_level<G, P, true>(p, tree, gl, done, slots, np_, lds_log, nm, target)
+        const LevelWinner w = root           ? scan_level<G, P, true, FWD>(p, tree, gl, done, slots, np_, lds_log, nm, target, pre, fw)
                               : p.sort_nodes ? scan_level<G, 1, false>(p, tree, gl, done, slots, np_, lds_log, nm, target)
                                              : scan_level<G, P, false>(p, tree, gl, done, slots, np_, lds_log, nm, target);
         const int k = w.k, wc = w.cc >> kPathShift;
@@ -641,8 +703,8 @@ __device__ __forceinline__ BackupPrefetchT<PB> backprop_prefetch(const PoolDev& 
 
 // Node.update_value (agent.py:119-123) on slot k of record r, plus what select will want of it next time.
 // c_old/vs_old: the slot before (vs_old ignored for an unvisited slot); rw: the node's reward.
-__device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, int c_old, double vs_old, double vin,
-                                            float rw, bool leaf, int nb, int hi0, double& mn_l, double& mx_l) {
+__device__ __forceinline__ double backup_slot(const PoolDev& p, char* r, int k, int c_old, double vs_old, double vin,
+                                              float rw, bool leaf, int nb, int hi0, double& mn_l, double& mx_l) {
     const int c = c_old + 1;
     const double vs = (c_old > 0 ? vs_old : 0.0) + vin;
     Slot* s = f_slots(p, r) + k;
@@ -663,7 +725,9 @@ __device__ __forceinline__ void backup_slot(const PoolDev& p, char* r, int k, in
     if (mean < mn_l) mn_l = mean;
     // ucb_score's exploitation term of this child (agent.py:188), normalised here when the bounds are known
     const double ex = (mean == mean) ? (double)rw + p.discount * mean : p.default_value;
-    s->q = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
+    const double q = p.has_bounds ? (ex - p.kmin) / (p.kmax - p.kmin) : ex;
+    s->q = q;
+    return q;
 }
 
 // A child slot at expansion: count 0, prior, action -- written as the WHOLE 24-byte slot (q and the child word as zeros:
@@ -713,9 +777,10 @@ __device__ __forceinline__ int sorted_slot_lds(int A, int i, float pi, const flo
 // pol_row: this tree's A priors or logits (global or LDS); rnew, value_f32: its scalarised reward and value.
 // lds_row: this group's TreeLds<G>::kRow floats of LDS (16-byte aligned), or nullptr (then PB must be 1, and the
 // softmax of an action axis wider than the group goes through global memory and a workgroup barrier).
-template <int G, bool LOGITS, int PB = 1>
+template <int G, bool LOGITS, int PB = 1, bool FWD = false>
 __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, int nb, const float* pol_row,
-                              float rnew, float value_f32, const BackupPrefetchT<PB>& pf, float* lds_row = nullptr) {
+                              float rnew, float value_f32, const BackupPrefetchT<PB>& pf, float* lds_row = nullptr,
+                              RootFwd* fw = nullptr) {
     using L = TreeLds<G>;
     const int A = p.A;
     const int len = pf.len;
@@ -800,6 +865,8 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
     const int top = len - 1;
     double mn_l = std::numeric_limits<double>::infinity();
     double mx_l = -std::numeric_limits<double>::infinity();
+    double q_pos0 = 0.0;                         // FWD: the new exploitation term of the path's first slot (lane 0 of the group)
+    bool fwd_ok = true;
     if (lds_row != nullptr && !__any(len > L::kPathCap)) {
         // every lane of the group replays the chain from the rewards staged in the group's LDS row and leaves the
         // value entering each position there
@@ -819,9 +886,12 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
             const int pos = gl + G * j;
-            if (active && pos < len)
-                backup_slot(p, rec(p, tree, pf.slot[j] >> kPathShift), pf.slot[j] & (kMaxActions - 1), pf.c[j], pf.vs[j],
-                            vins[pos], (pos == top) ? rnew : pf.rw[j], pos == top, nb, hi0, mn_l, mx_l);
+            if (active && pos < len) {
+                const double qn = backup_slot(p, rec(p, tree, pf.slot[j] >> kPathShift), pf.slot[j] & (kMaxActions - 1),
+                                              pf.c[j], pf.vs[j], vins[pos], (pos == top) ? rnew : pf.rw[j], pos == top, nb,
+                                              hi0, mn_l, mx_l);
+                if (FWD && j == 0) q_pos0 = qn;  // (position 0 is lane 0's first)
+            }
         }
     } else if (!__any(len > G)) {
         // every path of this wavefront fits one group: lane gl owns position gl, its slot came with the prefetch;
@@ -836,9 +906,10 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (j < len) v = (double)rj + p.discount * v;
         }
         if (has)
-            backup_slot(p, rec(p, tree, pf.slot[0] >> kPathShift), pf.slot[0] & (kMaxActions - 1), pf.c[0], pf.vs[0], vin,
-                        rw, gl == top, nb, hi0, mn_l, mx_l);
+            q_pos0 = backup_slot(p, rec(p, tree, pf.slot[0] >> kPathShift), pf.slot[0] & (kMaxActions - 1), pf.c[0],
+                                 pf.vs[0], vin, rw, gl == top, nb, hi0, mn_l, mx_l);
     } else {
+        fwd_ok = false;
         // long paths: groups of G positions from the leaf down, lane j of a round owns position top-base-j
         for (int base = 0;; base += G) {
             const bool more = base < len;
@@ -891,6 +962,18 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (mx_l > pf.mm_max) p.mm_max[tree] = mx_l;
             if (mn_l < pf.mm_min) p.mm_min[tree] = mn_l;
         }
+    }
+    if (FWD) {
+        // what the select that follows must know of this backup: lane 0 of the group owned the path's first slot
+        fw->ok = fwd_ok;
+        fw->k0 = __shfl(pf.slot[0] & (kMaxActions - 1), 0, G);
+        fw->c0 = __shfl(pf.c[0], 0, G) + 1;
+        fw->ch_set = len == 1;                        // the root's child is the new node's parent slot
+        fw->ch0 = (hi0 << kChildBits) | nb;
+        fw->q0 = __shfl(q_pos0, 0, G);
+        fw->root_count = pf.root_count + 1;
+        fw->mx = mx_l > pf.mm_max ? mx_l : pf.mm_max;
+        fw->mn = mn_l < pf.mm_min ? mn_l : pf.mm_min;
     }
     MZ_TRACE(4);                                 // backup: root and min/max updated
 }
