@@ -453,8 +453,8 @@ def timed_region(move, steps, warmup, world, with_net, event_every=10, sync_ever
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        # per-launch events on every event_every-th step; the tree-only moves bracket the run of fused steps on the next
-        move.run(timed_events=(i % event_every == 0) or ('run' if not with_net and i % event_every == 1 else False))
+        # per-launch events on every event_every-th step; the tree-only moves bracket the run of fused steps on the next two
+        move.run(timed_events=(i % event_every == 0) or ('run' if not with_net and i % event_every in (1, 2) else False))
         if sync_every and (i + 1) % sync_every == 0:
             torch.cuda.synchronize()
     if with_net:
@@ -501,9 +501,9 @@ def tree_roofline_leg(name, device, steps, seed):
     wl = dict(WORKLOADS[name])
     stride = max(1, wl['N'] // 10)
     move = SyntheticTreeMove(wl, device, seed, 1, stride)
-    move.hip_events.reserve(3 * (wl['N'] // stride + 2))
+    move.hip_events.reserve(9 * (wl['N'] // stride + 2))
     cost = event_record_cost(move.hip_events)
-    elapsed, sims, sum_d = timed_region(move, steps, 1, 1, False, event_every=max(2, steps))
+    elapsed, sims, sum_d = timed_region(move, steps, 2, 1, False, event_every=max(3, steps))   # two 'run' samples a leg
     assert sims == steps * wl['T'] * wl['N'], (sims, steps, wl)
     mean_d = sum_d / sims
     out = tree_roofline(move, wl, name, mean_d, cost)
