@@ -288,10 +288,10 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
  * launch: a workgroup keeps its 16 games from the first simulation to
  * the last, so no launch boundary, no host call and no other workgroup's data separates two simulations; so it is for
  * the Atari-shaped network (64 games a workgroup, pools of 18 actions), and for the TicTacToe network with the default
- * 16 lanes per tree (the four workgroups of 64 games stay resident and hand each other their results through their XCD's
- * L2 twice per simulation; if that ever fails to complete within a second the launch gives up and mz_pool_counters
- * reports MZ_ERR_HIP); other networks and pools run it as the sequence of mz_infer_recurrent_step launches.  net and pool must use the same device and
- * stream. */
+ * 16 lanes per tree and more than 2560 trees (the four workgroups of 64 games stay resident and hand each other their
+ * results through their XCD's L2 twice per simulation; if that ever fails to complete within a second the launch gives
+ * up and mz_pool_counters reports MZ_ERR_HIP); other networks and pools -- smaller TicTacToe batches among them -- run it
+ * as the sequence of mz_infer_recurrent_step launches.  net and pool must use the same device and stream. */
 int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulations, int32_t final_select,
                            float* hidden_base, int32_t* parent_block, int64_t block_stride, int32_t* action,
                            float* out_reward, float* out_value, float* out_logits, int64_t out_stride,
