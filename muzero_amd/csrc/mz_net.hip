@@ -2617,15 +2617,31 @@ constexpr int kAtariStageFloats = 16384;         // one split-f16 128 x 128 matr
 // tiles, which are dead by then.  The backup's inputs are requested at the start and land while the network computes.
 // parent_block / action are then read at the start and rewritten at the end, each workgroup its own 64 games.
 constexpr int kAtariTreeG = 8, kAtariTreeP = 4;     // 18 children at the root: one round of 4 slots per lane
+// The pool descriptor (65 scalars) read from its image in device memory through a pointer the compiler cannot see through:
+// what a run kernel holds by value for a whole move crowds the scalar registers of everything in between.
+__device__ __forceinline__ PoolDev load_pool_image(const PoolDev* pool_image) {
+    struct PoolWords {
+        int w[sizeof(PoolDev) / sizeof(int)];
+    };
+    typedef const __attribute__((address_space(4))) int* PoolImage;
+    PoolImage image = (PoolImage) reinterpret_cast<const int*>(pool_image);
+    asm volatile("" : "+s"(image));
+    PoolWords words;
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(PoolDev) / sizeof(int)); ++j) words.w[j] = image[j];
+    return __builtin_bit_cast(PoolDev, words);
+}
 template <bool INITIAL, int FUSE>
 __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float* __restrict__ in_base, int* parent_block,
                                            long block_stride, int* action, float* __restrict__ out_hidden,
                                            float* __restrict__ out_reward, float* __restrict__ out_value,
                                            float* __restrict__ out_logits, float* __restrict__ out_value_raw,
-                                           const PoolDev& p, int nb, bool do_select = true, bool keep_out = true,
-                                           LdsLog staged_log = nullptr) {
+                                           const PoolDev& p_arg, int nb, bool do_select = true, bool keep_out = true,
+                                           LdsLog staged_log = nullptr, const PoolDev* p_image = nullptr) {
     constexpr int ROWS = 64;
     constexpr int TG = kAtariTreeG, TPB = TreeLds<TG>::kPB;
+    // p_image: read the descriptor where it is used (the start and the tree step), not across the network's stages
+    const PoolDev p = p_image != nullptr ? load_pool_image(p_image) : p_arg;
     static_assert(ROWS * TG == kThreadsW, "one pass of the workgroup covers its 64 trees");
     __shared__ __attribute__((aligned(16))) _Float16 sT[4][ROWS * kLdW];      // X0, X1, Y0, Y1
     __shared__ float sRew[8 * ROWS];                 // reward-head partials of the eight waves' column ranges
@@ -2873,6 +2889,8 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
         double* s_log = reinterpret_cast<double*>(rows + ROWS * TreeLds<TG>::kRow);
         // the log table: staged by the caller once for all its simulations (atari_run_kernel), or here, over the tiles
         // (the barrier before the output stores has ended every read of them)
+        const PoolDev p2 = p_image != nullptr ? load_pool_image(p_image) : p_arg;
+        const PoolDev& p = p2;
         const LdsLog lds_log = staged_log != nullptr ? staged_log : stage_log_table(p, s_log);
         const float* mine = sOut[tid / TG];
         backprop_tree<TG, true, TPB>(p, tree, tree_active, tgl, nb, mine + 1, mine[19], mine[0], pf,
@@ -2902,7 +2920,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_kernel(AtariDev w, int B, 
 // rows are its own from the first simulation to the last (the rows a simulation gathers were written by this workgroup:
 // the barrier at the end of a simulation publishes them), so no launch boundary and no other workgroup's deepest tree
 // separates two simulations.  Outputs and traces as in cartpole16_run_kernel.
-__global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, PoolDev p, int nb0, int nsim, int final_select,
+__global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, const PoolDev* pool_image, int T, int nb0, int nsim, int final_select,
                                                                  float* hidden_base, int* parent_block, long block_stride,
                                                                  int* action, float* out_reward, float* out_value,
                                                                  float* out_logits, long out_stride, int* trace_parent,
@@ -2912,10 +2930,14 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
     const int row0 = blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const int b = row0 + threadIdx.x;
-        s_sel[0][threadIdx.x] = b < p.T ? parent_block[b] : -1;
-        s_sel[1][threadIdx.x] = b < p.T ? action[b] : -1;
+        s_sel[0][threadIdx.x] = b < T ? parent_block[b] : -1;
+        s_sel[1][threadIdx.x] = b < T ? action[b] : -1;
     }
-    const LdsLog run_log = stage_log_table(p, s_log_run);       // never nullptr here: the host checked N + 2 <= kLogLds
+    LdsLog run_log;                                   // never nullptr here: the host checked N + 2 <= kLogLds
+    {
+        const PoolDev p0 = load_pool_image(pool_image);         // (the descriptor is re-read where the body uses it)
+        run_log = stage_log_table(p0, s_log_run);
+    }
     // the body indexes both by game: game b of this workgroup is entry b - row0 of the LDS copies
     int* const sel_parent = &s_sel[0][0] - row0;
     int* const sel_action = &s_sel[1][0] - row0;
@@ -2924,20 +2946,21 @@ __global__ __launch_bounds__(kThreadsW, 1) void atari_run_kernel(AtariDev w, Poo
         asm volatile("" ::: "memory");
         if (trace_parent != nullptr && threadIdx.x < 64) {
             const int b = row0 + threadIdx.x;
-            if (b < p.T) {
-                trace_parent[(size_t)i * p.T + b] = s_sel[0][threadIdx.x];
-                trace_action[(size_t)i * p.T + b] = s_sel[1][threadIdx.x];
+            if (b < T) {
+                trace_parent[(size_t)i * T + b] = s_sel[0][threadIdx.x];
+                trace_action[(size_t)i * T + b] = s_sel[1][threadIdx.x];
             }
         }
         float* oh = hidden_base + (size_t)(nb0 + i) * block_stride;
         float* orw = out_reward + (size_t)i * out_stride;
         float* ov = out_value + (size_t)i * out_stride;
         float* ol = out_logits + (size_t)i * out_stride * 18;
-        atari_body<false, 2>(w, p.T, hidden_base, sel_parent, block_stride, sel_action, oh, orw, ov, ol, nullptr, p, nb0 + i,
-                             i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim, run_log);
+        atari_body<false, 2>(w, T, hidden_base, sel_parent, block_stride, sel_action, oh, orw, ov, ol, nullptr, PoolDev{},
+                             nb0 + i, i + 1 < nsim || final_select != 0, out_stride != 0 || i + 1 == nsim, run_log,
+                             pool_image);
         __syncthreads();
     }
-    if (final_select != 0 && threadIdx.x < 64 && row0 + threadIdx.x < p.T) {
+    if (final_select != 0 && threadIdx.x < 64 && row0 + threadIdx.x < T) {
         parent_block[row0 + threadIdx.x] = s_sel[0][threadIdx.x];
         action[row0 + threadIdx.x] = s_sel[1][threadIdx.x];
     }
@@ -3813,8 +3836,10 @@ int mz_infer_recurrent_run(mz_net_t* net, mz_pool_t* pool, int32_t num_simulatio
         int s = mz_pool_begin_run(pool, num_simulations, final_select != 0, &nb0);
         if (s != MZ_OK) return s;
         MZ_HIP(hipSetDevice(net->device));
+        const PoolDev* image = static_cast<const PoolDev*>(mz_pool_device_image(pool));
+        if (!image) return MZ_ERR_HIP;
         atari_run_kernel<<<(T + 63) / 64, kThreadsW, 0, net->stream>>>(
-            net->atari, pool->dev, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
+            net->atari, image, T, nb0, num_simulations, final_select, hidden_base, parent_block, (long)block_stride, action,
             out_reward, out_value, out_logits, (long)out_stride, trace_parent, trace_action);
         s = launch_status("recurrent inference + tree step, all simulations");
         if (s != MZ_OK) return s;
