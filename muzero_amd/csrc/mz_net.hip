@@ -902,6 +902,202 @@ __global__ __launch_bounds__(kThreads, 2) void ttt_initial_kernel_h(TttDev w, in
     note_range(vmax, w.range_flag);
 }
 
+// One 64 x 128 split tile times one 128 x 128 split matrix on the job kernel's geometry: wave v owns columns 16 v .. + 15 of
+// all 64 rows as four 16-row blocks (v_mfma_f32_16x16x32_f16, weights as the row operand), h x h terms into acc, the
+// cross terms into acx (fold4 at the end of the accumulation).  `next`: the matrix that replaces b in place, fragment by
+// fragment as the k-steps consume it (nullptr: b stays).
+template <bool NEXT = false>
+__device__ __forceinline__ void mma_tile_w(const _Float16* tile, BFragW& b, f32x4 (&acc)[4], f32x4 (&acx)[4], int n16, int g,
+                                           const float4* next = nullptr) {
+    const _Float16* ap = tile + n16 * kLdW + 8 * g;
+    float4 af[2][4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        af[0][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW);
+        af[0][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                af[(s + 1) & 1][m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 32 * (s + 1));
+                af[(s + 1) & 1][m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * kLdW + 128 + 32 * (s + 1));
+            }
+        }
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.v[2 * s]), bl = __builtin_bit_cast(f16x8, b.v[2 * s + 1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, af[s & 1][m][0]), al = __builtin_bit_cast(f16x8, af[s & 1][m][1]);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[m], 0, 0, 0);
+            acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[m], 0, 0, 0);
+            acx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx[m], 0, 0, 0);
+        }
+        if (NEXT) {
+            b.v[2 * s] = next[(2 * s) * 512];
+            b.v[2 * s + 1] = next[(2 * s + 1) * 512];
+        }
+        // pin the interleave (left alone the scheduler sinks every fragment read to its first use and each group of
+        // MFMAs waits out an LDS latency): the next k-step's eight fragment reads, this k-step's twelve MFMAs, the loads
+        if (s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        if (NEXT) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+}
+
+// Initial inference for the batches of the 64-game jobs: 64 games x a group of cells per 512-thread workgroup, the job
+// kernel's grid (ttt_job_of_block), tile layout and MFMA geometry.  The 32-game kernel above takes 21 us for 4096 games
+// -- the time of two thirds of a simulation for a quarter of its arithmetic: a K = 27 conv on the VALU with 135 LDS
+// reads a thread and cell, and every MFMA stage cold behind a barrier.  Here
+//   * the conv of cell c is ONE split-f16 k-step over the game's observation row [cell'][plane] (27 values, padded to 32)
+//     with a per-cell 32 x 128 matrix that holds the tap reaching cell' from c and zeros elsewhere (rep_conv_c, packed by
+//     mz_net_create): twelve MFMAs a wavefront;
+//   * the cells are software-pipelined over two conv tiles and two hidden tiles: between two barriers a workgroup runs the
+//     prediction-conv term of cell j-1, the Dense of cell j, the conv of cell j+1 and the Dense epilogue of cell j, then
+//     copies cell j's hidden rows out under the next section -- one barrier a cell, 96 MFMAs a wavefront between them;
+//   * a workgroup loads every weight fragment once for its 64 games (the prediction-conv fragments in place, under the
+//     MFMAs that consume their predecessors).
+// Same layers per cell as above (games/tictactoe.py:182-184, :201); the partial of a job is accumulated over its cells in
+// the MFMA accumulators and folded once.  rep_dense_s: the representation Dense as Packer::add_split16 fragments.
+template <bool SPLIT_IO>
+__global__ __launch_bounds__(kThreadsW, 1) void ttt_initial_kernel_w(TttDev w, const float* __restrict__ rep_dense_s,
+                                                                     const float* __restrict__ rep_conv_c, int B,
+                                                                     const float* __restrict__ observation,
+                                                                     float* __restrict__ out_hidden,
+                                                                     float* __restrict__ ppart) {
+    constexpr int ROWS = 64, TILE = ROWS * kLdW;
+    constexpr int kLdO = 72;       // observation row stride in halfs: [32 h | 32 l] + 8
+    __shared__ __attribute__((aligned(16))) _Float16 sX[2 * TILE];
+    __shared__ __attribute__((aligned(16))) _Float16 sH[2 * TILE];
+    __shared__ __attribute__((aligned(16))) _Float16 sObs[ROWS * kLdO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4, lcol = wave * 16 + 4 * g;
+    int job, rb;
+    ttt_job_of_block<4>(job, rb);
+    if (rb >= (B + ROWS - 1) / ROWS) return;         // grid padding (uniform per workgroup)
+    const int row0 = rb * ROWS;
+    const int ncell = w.job_cells[job][2] >= 0 ? 3 : 2;
+    float vmax = 0.f;
+    float obs[4];                                    // 64 rows x 32 k's: the split image of the observation rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                    // (unconditional loads from clamped addresses, all four requested
+        const int idx = tid + kThreadsW * i, r = idx >> 5, k = idx & 31;      // before the first is used)
+        obs[i] = observation[(size_t)min(row0 + r, B - 1) * 27 + min(k, 26)];
+    }
+    asm volatile("" : "+v"(obs[0]), "+v"(obs[1]), "+v"(obs[2]), "+v"(obs[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreadsW * i, r = idx >> 5, k = idx & 31;
+        const float v = k < 27 && row0 + r < B ? obs[i] : 0.f;
+        _Float16 h, l;
+        split_f16(v, h, l);
+        vmax = fmaxf(vmax, fabsf(v));
+        sObs[r * kLdO + k] = h;
+        sObs[r * kLdO + 32 + k] = l;
+    }
+    const float4* const cw = reinterpret_cast<const float4*>(rep_conv_c) + wave * 64 + lane;
+    const float4* const pw = reinterpret_cast<const float4*>(w.pred_conv_s) + wave * 64 + lane;
+    const float4 cb = *reinterpret_cast<const float4*>(w.rep_conv_b + lcol);
+    const float4 db = *reinterpret_cast<const float4*>(w.rep_dense_b + lcol);
+    // relu(conv + bias) of one cell into a tile as split images; ch / cl: the cell's matrix fragments (h | l)
+    auto conv_cell = [&](const float4 ch, const float4 cl, _Float16* tile) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, ch), bl = __builtin_bit_cast(f16x8, cl);
+        const _Float16* ap = sObs + n16 * kLdO + 8 * g;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(ap + m * 16 * kLdO));
+            const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(ap + m * 16 * kLdO + 32));
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, a, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, x, 0, 0, 0);
+            a += x * kUnsplit;
+            const float v[4] = {fmaxf(a[0] + cb.x, 0.f), fmaxf(a[1] + cb.y, 0.f), fmaxf(a[2] + cb.z, 0.f),
+                                fmaxf(a[3] + cb.w, 0.f)};
+            uint2 h, l;
+            split4(v, h, l, vmax);
+            _Float16* row = tile + (16 * m + n16) * kLdW + lcol;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
+        }
+    };
+    // relu(Dense + bias) = hidden[cell] into a tile as split images (and, unsplit, to the f32 rows)
+    auto dense_out = [&](f32x4 (&acc)[4], const f32x4 (&acx)[4], _Float16* tile, int cell) {
+        fold4(acc, acx);
+        float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float x[4] = {fmaxf(acc[m][0] + db.x, 0.f), fmaxf(acc[m][1] + db.y, 0.f), fmaxf(acc[m][2] + db.z, 0.f),
+                                fmaxf(acc[m][3] + db.w, 0.f)};
+            uint2 h, l;
+            split4(x, h, l, vmax);
+            _Float16* row = tile + (16 * m + n16) * kLdW + lcol;
+            *reinterpret_cast<uint2*>(row) = h;
+            *reinterpret_cast<uint2*>(row + 128) = l;
+            if (!SPLIT_IO && row0 + 16 * m + n16 < B)
+                *reinterpret_cast<float4*>(ocell + (unsigned)(16 * m + n16) * 1152u + lcol) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+    };
+    // a complete hidden tile is the row image the split workspace wants: 16 bytes a thread
+    auto copy_out = [&](const _Float16* tile, int cell) {
+        if (!SPLIT_IO) return;
+        float* const ocell = out_hidden + (size_t)row0 * 1152 + cell * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreadsW * i, r = idx >> 5, q = idx & 31;
+            if (row0 + r < B)
+                *reinterpret_cast<float4*>(ocell + (unsigned)r * 1152u + q * 4) =
+                    *reinterpret_cast<const float4*>(tile + r * kLdW + q * 8);
+        }
+    };
+    const int cell0 = w.job_cells[job][0], cell1 = w.job_cells[job][1];
+    float4 ch = cw[(size_t)cell0 * 1024], cl = cw[(size_t)cell0 * 1024 + 512];
+    BFragW bd, bp;
+    load_bw(bd, rep_dense_s, lane, wave);            // the same Dense for every cell
+    __syncthreads();                                 // sObs
+    conv_cell(ch, cl, sX);
+    ch = cw[(size_t)cell1 * 1024];
+    cl = cw[(size_t)cell1 * 1024 + 512];
+    load_bw(bp, w.pred_conv_s + (size_t)cell0 * 16384, lane, wave);
+    f32x4 accp[4], accpx[4], acc[4], acx[4];
+    zero4(accp);
+    zero4(accpx);
+    zero4(acc);
+    zero4(acx);
+    __syncthreads();
+    // section 0: Dense of the first cell, conv of the second
+    mma_tile_w(sX, bd, acc, acx, n16, g);
+    conv_cell(ch, cl, sX + TILE);
+    dense_out(acc, acx, sH, cell0);
+    __syncthreads();
+    copy_out(sH, cell0);
+#pragma unroll 1
+    for (int j = 1; j < ncell; ++j) {
+        const int cell = w.job_cells[job][j];        // kernel argument: a scalar load
+        const int nc = j + 1 < ncell ? w.job_cells[job][j + 1] : cell;
+        ch = cw[(size_t)nc * 1024];
+        cl = cw[(size_t)nc * 1024 + 512];
+        zero4(acc);
+        zero4(acx);
+        // the previous cell's term of the prediction conv (its fragments make way for this cell's), this cell's Dense
+        mma_tile_w<true>(sH + ((j - 1) & 1) * TILE, bp, accp, accpx, n16, g, pw + (size_t)cell * 4096);
+        mma_tile_w(sX + (j & 1) * TILE, bd, acc, acx, n16, g);
+        if (j + 1 < ncell) conv_cell(ch, cl, sX + ((j + 1) & 1) * TILE);
+        dense_out(acc, acx, sH + (j & 1) * TILE, cell);
+        __syncthreads();
+        copy_out(sH + (j & 1) * TILE, cell);
+    }
+    mma_tile_w(sH + ((ncell - 1) & 1) * TILE, bp, accp, accpx, n16, g);
+    fold4(accp, accpx);
+    float* const pjob = ppart + (size_t)row0 * 1152 + job * 128;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (row0 + 16 * m + n16 < B)
+            *reinterpret_cast<f32x4*>(pjob + (unsigned)(16 * m + n16) * 1152u + lcol) = accp[m];
+    note_range(vmax, w.range_flag);
+}
+
 // Prediction head of 16 games by one 256-thread workgroup: relu(sum of the NP partial products + bias)
 // (games/tictactoe.py:201) -> Dense 128 -> 128 relu (:204) -> value (tanh, :206) and the 9 policy logits (:208), and
 // the reward head's tanh over the 9 per-cell partial dots (:193-195).  Split-f16 arithmetic like the job kernel
@@ -1106,6 +1302,34 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
             if (!INITIAL) out_reward[b] = sOut[tid][10];
         }
     }
+}
+
+// Kernel B of a native move's initial inference fused with what follows it: the root expansion over the logits just
+// computed, the Dirichlet noise and the first selection (expand_roots_kernel<16, true, 1>'s code, mz_tree_dev.h, on the same
+// 16 lanes per game: bit-identical trees).  One launch boundary less per move.
+__global__ __launch_bounds__(kThreads) void ttt_head_roots_kernel(TttDev w, PoolDev p, const float* __restrict__ ppart,
+                                                                  float* out_value, float* out_logits, const int* legal,
+                                                                  const int* n_legal, const double* noise, double frac,
+                                                                  int* out_parent, int* out_action) {
+    constexpr int G = 16;
+    __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
+    __shared__ float sOut[16][12];
+    const int row0 = blockIdx.x * 16, tid = threadIdx.x;
+    HeadW hw;
+    ttt_head_weights(w, hw);
+    ttt_head16<4, false>(w, p.T, row0, ppart, nullptr, sBuf[0], sBuf[1], sOut, hw);
+    if (tid < 16 * 10) {
+        const int b = row0 + tid / 10, o = tid % 10;
+        if (b < p.T) {
+            if (o == 9) out_value[b] = sOut[tid / 10][9];
+            else out_logits[(size_t)b * 9 + o] = sOut[tid / 10][o];
+        }
+    }
+    // the tree code reads the logits where the caller gets them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    expand_roots_tree<G, true, 1>(p, row0 + tid / G, tid % G, out_logits, legal, n_legal, noise, frac, out_parent, out_action);
 }
 
 // Kernel B fused with the tree step (expand + backprop of this simulation, select of the next: mz_step_logits).
@@ -3010,6 +3234,23 @@ struct Packer {
         memcpy(f.data(), p.data(), f.size() * sizeof(float));
         return add(f);
     }
+    // W[32][128] row-major -> the one k-step of add_split16's layout: 16-byte entry [plane][block = n / 16][lane = 16 g +
+    // n % 16] holds the 8 halfs k = 8g .. +7 of column n (4096 floats)
+    size_t add_split16_k32(const float* W) {
+        std::vector<_Float16> p((size_t)32 * 128 * 2, (_Float16)0.f);
+        for (int k = 0; k < 32; ++k)
+            for (int n = 0; n < 128; ++n) {
+                const float w = W[(size_t)k * 128 + n];
+                const _Float16 h = (_Float16)w;
+                const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+                const int g = k / 8, i = k % 8, lane = 16 * g + n % 16, blk = n / 16;
+                p[(((size_t)0 * 8 + blk) * 64 + lane) * 8 + i] = h;
+                p[(((size_t)1 * 8 + blk) * 64 + lane) * 8 + i] = l;
+            }
+        std::vector<float> f((size_t)32 * 128);
+        memcpy(f.data(), p.data(), f.size() * sizeof(float));
+        return add(f);
+    }
     // W[128][128] row-major -> split-f16 MFMA fragments for v_mfma_f32_32x32x16_f16, the size of the f32 matrix:
     // 16-byte entry [j = 2t + plane][n][g] holds the 8 halfs k = 16t + 8g .. +7 of column n; plane 0 = h = f16(w),
     // plane 1 = l = f16((w - h) * 2048).  w ~= h + l/2048 to 22 mantissa bits.
@@ -3044,6 +3285,8 @@ struct mz_net {
     int64_t training_steps = 0;
     float* weights = nullptr;      // one device allocation holding every packed table
     TttDev ttt{};
+    const float* ttt_rep_dense_s = nullptr;   // representation Dense as add_split16 fragments (ttt_initial_kernel_w)
+    const float* ttt_rep_conv_c = nullptr;    // [9 cells] x the 3 -> 128 conv as a 32 x 128 matrix over the observation row
     CartDev cart{};
     AtariDev atari{};
     float* ppart = nullptr;        // TicTacToe scratch: [cap][9][128] prediction-conv partials
@@ -3287,6 +3530,20 @@ int mz_net_create(int32_t kind, const float* wh, int64_t num_weights, int64_t tr
         if (o_dense != o_conv + 9 * 16384 || o_pred != o_dense + 16384) {
             delete net;
             return mz::fail(MZ_ERR_STATE, "packed TicTacToe stage matrices are not consecutive");
+        }
+        put(net->ttt_rep_dense_s, pk.add_split16(rep_dense, 128, 128));
+        // the 3 x 3 same conv of cell c as ONE matrix product over the game's observation row [cell'][plane] (K = 27, padded
+        // to 32): row cell' * 3 + p = the tap that reaches cell' from c, zero where cell' is no neighbour of c
+        for (int c = 0; c < 9; ++c) {
+            std::vector<float> wc((size_t)32 * 128, 0.f);
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ni = c / 3 + tp / 3 - 1, nj = c % 3 + tp % 3 - 1;
+                if (ni < 0 || ni >= 3 || nj < 0 || nj >= 3) continue;
+                for (int pl = 0; pl < 3; ++pl)
+                    memcpy(&wc[(size_t)((ni * 3 + nj) * 3 + pl) * 128], rep_conv + (size_t)(tp * 3 + pl) * 128, 128 * sizeof(float));
+            }
+            const size_t o = pk.add_split16_k32(wc.data());
+            if (c == 0) put(net->ttt_rep_conv_c, o);
         }
     } else if (kind == MZ_NET_ATARI_SHAPED) {
         AtariDev& a = net->atari;
@@ -3533,8 +3790,19 @@ int mz_net_set_mid_event(mz_net_t* net, void* hip_event) {
 // doubles the number of workgroups, which wins while a 64-row grid cannot fill the 256 CUs.
 static int tile_rows(int batch) { return (batch + 63) / 64 >= 512 ? 64 : 32; }
 
+static int ttt_mb(const mz_net* net, int batch);
+
+// what follows the initial inference of a native move on the trees (mz_net_begin_move_roots)
+struct RootsArgs {
+    mz_pool* pool;
+    const int32_t *legal, *n_legal;
+    const double* noise;
+    double frac;
+    int32_t *out_parent, *out_action;
+};
+
 static int infer_initial(mz_net_t* net, int32_t batch, const float* observation, float* out_hidden, float* out_value,
-                         float* out_logits, float* out_value_raw, bool split_hidden) {
+                         float* out_logits, float* out_value_raw, bool split_hidden, const RootsArgs* roots = nullptr) {
     MZ_REQUIRE(net != nullptr, "net is NULL");
     MZ_REQUIRE(batch >= 0, "batch must be >= 0 (got %d)", batch);
     net->hidden_split = false;   // a move starts here; a native move that failed half way may have left it set
@@ -3549,15 +3817,27 @@ static int infer_initial(mz_net_t* net, int32_t batch, const float* observation,
         if (s != MZ_OK) return s;
         const int nhb = (batch + 15) / 16;
         const int nrb32 = (batch + 31) / 32;
-        if (split_hidden)
+        if (ttt_mb(net, batch) == 4) {               // the batches of the 64-game jobs
+            if (split_hidden)
+                ttt_initial_kernel_w<true><<<ttt_job_grid(batch, 4), kThreadsW, 0, st>>>(
+                    net->ttt, net->ttt_rep_dense_s, net->ttt_rep_conv_c, batch, observation, out_hidden, net->ppart);
+            else
+                ttt_initial_kernel_w<false><<<ttt_job_grid(batch, 4), kThreadsW, 0, st>>>(
+                    net->ttt, net->ttt_rep_dense_s, net->ttt_rep_conv_c, batch, observation, out_hidden, net->ppart);
+        } else if (split_hidden)
             ttt_initial_kernel_h<true><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
                                                                                    out_hidden, net->ppart);
         else
             ttt_initial_kernel_h<false><<<32 * ((nrb32 + 7) / 8), kThreads, 0, st>>>(net->ttt, batch, observation,
                                                                                     out_hidden, net->ppart);
         if (net->mid_event) MZ_HIP(hipEventRecord(net->mid_event, st));
-        ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
-                                                          out_value, out_logits, out_value_raw);
+        if (roots != nullptr)
+            ttt_head_roots_kernel<<<nhb, kThreads, 0, st>>>(net->ttt, roots->pool->dev, net->ppart, out_value, out_logits,
+                                                           roots->legal, roots->n_legal, roots->noise, roots->frac,
+                                                           roots->out_parent, roots->out_action);
+        else
+            ttt_head_kernel<true, 4><<<nhb, kThreads, 0, st>>>(net->ttt, batch, nullptr, net->ppart, net->rpart, nullptr,
+                                                              out_value, out_logits, out_value_raw);
     } else if (net->kind == MZ_NET_ATARI_SHAPED) {
         atari_kernel<true><<<(batch + 63) / 64, kThreadsW, 0, st>>>(net->atari, batch, observation, nullptr, 0, nullptr,
                                                                    out_hidden, nullptr, out_value, out_logits, out_value_raw);
@@ -3714,6 +3994,32 @@ __attribute__((visibility("hidden"))) int mz_net_begin_move(mz_net* net, int bat
     const int s = infer_initial(net, batch, observation, hidden_block0, out_value, out_logits, nullptr, split);
     if (s == MZ_OK && batch > 0) net->hidden_split = split;
     return s;
+}
+// mz_net_begin_move followed by mz_expand_roots_noise with the first selection (logits = the inference's).  TicTacToe on a
+// 16-lane pool: the head kernel of the initial inference goes on into the root expansion (ttt_head_roots_kernel).
+__attribute__((visibility("hidden"))) int mz_net_begin_move_roots(mz_net* net, mz_pool* pool, int batch,
+                                                                  const float* observation, float* hidden_block0,
+                                                                  float* out_value, float* out_logits, const int32_t* legal,
+                                                                  const int32_t* n_legal, const double* noise, double frac,
+                                                                  int32_t* out_parent, int32_t* out_action) {
+    MZ_REQUIRE(net != nullptr && pool != nullptr, "net/pool is NULL");
+    MZ_REQUIRE(out_parent != nullptr && out_action != nullptr, "out_parent_block/out_action is NULL");
+    const bool fused = net->kind == MZ_NET_TICTACTOE && pool->G == 16 && pool->P == 1 && pool->dev.A == 9 &&
+                       pool->dev.T == batch && batch > 0 && pool->device == net->device && pool->stream == net->stream;
+    if (!fused) {
+        const int s = mz_net_begin_move(net, batch, observation, hidden_block0, out_value, out_logits);
+        if (s != MZ_OK) return s;
+        return mz_expand_roots_noise(pool, out_logits, 1, legal, n_legal, noise, frac, out_parent, out_action);
+    }
+    if (pool->dev.N < 1) return mz::fail(MZ_ERR_STATE, "pool is full: it holds no simulation");
+    const RootsArgs roots{pool, legal, n_legal, noise, frac, out_parent, out_action};
+    const int s = infer_initial(net, batch, observation, hidden_block0, out_value, out_logits, nullptr, true, &roots);
+    if (s != MZ_OK) return s;
+    net->hidden_split = true;
+    pool->blocks_in_use = 1;     // (what expand_roots_impl leaves behind)
+    pool->select_launches++;
+    pool->pending = true;
+    return MZ_OK;
 }
 __attribute__((visibility("hidden"))) void mz_net_end_move(mz_net* net) { net->hidden_split = false; }
 __attribute__((visibility("hidden"))) int mz_net_hidden_size_of(const mz_net* net) { return mz_net_hidden_size(net->kind); }

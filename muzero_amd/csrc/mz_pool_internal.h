@@ -47,6 +47,11 @@ struct mz_net;
 extern "C" int mz_net_begin_move(mz_net* net, int batch, const float* observation, float* hidden_block0, float* out_value,
                                  float* out_logits);
 extern "C" void mz_net_end_move(mz_net* net);
+// mz_net_begin_move, then mz_expand_roots_noise (below) on the logits it produced, with the first selection: as few launches
+// as the network allows
+extern "C" int mz_net_begin_move_roots(mz_net* net, mz_pool* pool, int batch, const float* observation, float* hidden_block0,
+                                       float* out_value, float* out_logits, const int32_t* legal, const int32_t* n_legal,
+                                       const double* noise, double frac, int32_t* out_parent_block, int32_t* out_action);
 
 // what mz_search_move checks a network handle against (mz_net.hip)
 extern "C" int mz_net_hidden_size_of(const mz_net* net);

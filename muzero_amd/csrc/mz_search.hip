@@ -45,9 +45,9 @@ extern "C" int mz_search_move(mz_pool_t* pool, mz_net_t* net, const mz_move_io_t
         mz_net_t* net;
         ~EndMove() { mz_net_end_move(net); }
     } end_move{net};
-    MZ_TRY_(mz_net_begin_move(net, T, io->observation, io->hidden, io->value, io->logits));
-    MZ_TRY_(mz_expand_roots_noise(pool, io->logits, 1, io->legal, io->n_legal, io->noise, io->noise_frac, io->parent_block,
-                                  io->action));                      // ... and the first selection
+    // ... then the root expansion, the noise and the first selection
+    MZ_TRY_(mz_net_begin_move_roots(net, pool, T, io->observation, io->hidden, io->value, io->logits, io->legal, io->n_legal,
+                                    io->noise, io->noise_frac, io->parent_block, io->action));
     if (!ev || mz_net_run_is_one_launch(net, pool)) {
         // run_mcts as one call (one launch where the network and pool allow it).  Timing events then bracket the whole
         // run: those of the first simulation that has any are recorded, [0] before it, [1] and [2] after it.

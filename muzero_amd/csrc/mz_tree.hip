@@ -301,69 +301,7 @@ __global__ __launch_bounds__(kBlockThreads) void expand_roots_kernel(PoolDev p, 
                                                                      double frac, int* out_parent = nullptr,
                                                                      int* out_action = nullptr) {
     const int gid = blockIdx.x * kBlockThreads + threadIdx.x;
-    const int tree = gid / G, gl = gid % G;
-    const int A = p.A;
-    const bool in = tree < p.T;
-    int n = 0;
-    if (in) {
-        n = n_legal ? n_legal[tree] : A;
-        if (n < 0 || n > A) {
-            n = 0;
-            if (gl == 0) atomicOr(p.err_flag, 2);
-        }
-    }
-    char* r = rec(p, in ? tree : 0, 0);
-    // staging for the exp terms over the FULL action axis + the leaf sums: the root's backup half, unused until the
-    // first backup
-    float* stage = reinterpret_cast<float*>(f_back(p, r));
-    float total = 1.f;
-    if (LOGITS) {
-        // masked_policy over the FULL action axis (network.py:143-146): exp(logit) at legal actions, 0 elsewhere
-        if (in && n > 0)
-            for (int k = gl; k < A; k += G) stage[k] = 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (in && n > 0) {
-            for (int k = gl; k < n; k += G) {
-                const int a = legal ? legal[(size_t)tree * A + k] : k;
-                if (a >= 0 && a < A) stage[a] = expf(pol[(size_t)tree * A + a]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        total = numpy_sum_f32<G>(p, stage, stage + A, (in && n > 0) ? gl : 1 << 30);
-    }
-    if (!in) return;                       // (whole groups: a tree's lanes leave together)
-    Slot* slots = f_slots(p, r);
-    for (int k = gl; k < n; k += G) {
-        int a = legal ? legal[(size_t)tree * A + k] : k;
-        if (a < 0 || a >= A) {
-            a = 0;
-            atomicOr(p.err_flag, 4);
-        }
-        const float pk = LOGITS ? stage[k] / total : pol[(size_t)tree * A + k];   // child k <- policy[k] (trap T5)
-        slots[k].count = 0;
-        slots[k].prior = pk;
-        slots[k].act = a;
-        const double rp = (double)pk;
-        p.root_prior[(size_t)tree * A + k] =
-            noise ? rp * (1 - frac) + noise[(size_t)tree * A + k] * frac : rp;     // agent.py:175 (fp64, uncontracted)
-    }
-    if (gl == 0) {
-        p.n_root[tree] = n;
-        p.root_count[tree] = 0;
-        p.root_vsum[tree] = 0.0;
-        p.mm_min[tree] = std::numeric_limits<double>::infinity();    // utils.py:60-61
-        p.mm_max[tree] = -std::numeric_limits<double>::infinity();
-        p.path_len[tree] = 0;
-    }
-    if constexpr (P > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        select_tree<G, P>(p, tree, n > 0, gl, out_parent, out_action, nullptr);
-    }
+    expand_roots_tree<G, LOGITS, P>(p, gid / G, gid % G, pol, legal, n_legal, noise, frac, out_parent, out_action);
 }
 
 __global__ void root_noise_kernel(PoolDev p, const double* noise, double frac) {

@@ -72,6 +72,32 @@ def test_initial_and_recurrent_inference(kind, B):
     assert outs[B - 1].value == float(out2.batch_value_scalar[B - 1])
 
 
+@pytest.mark.parametrize('B', [1, 63, 65, 200, 2600])
+def test_tictactoe_initial_inference_of_the_64_game_jobs(B):
+    """Batches beyond 2560 games take ttt_initial_kernel_w (64 games x a group of cells per workgroup, the 3 -> 128 conv
+    as one MFMA k-step over the observation row); set_job_rows(64) selects it for any batch.  Ragged batches, general
+    (non 0/1) observation values, and the recurrent step that reads the hidden rows it wrote."""
+    net, ref = make('tictactoe')
+    rng = np.random.default_rng(1000 + B)
+    if B <= 2560:
+        net.set_job_rows(64)
+    obs = observations('tictactoe', B, rng)
+    if B == 65:      # the planes are 0/1 in the game; the kernel splits any f32 value
+        obs = (obs + rng.standard_normal(obs.shape) * 0.37).astype(np.float32)
+    out = net.initial_inference(obs)
+    h, v, logits, raw = ref.initial_inference(obs)
+    close(out.batch_hidden_state, h)
+    close(out.batch_value_scalar, v)
+    close(out.batch_policy_logits, logits)
+    action = rng.integers(0, 9, size=B)
+    out2 = net.recurrent_inference(out.batch_hidden_state, action)
+    h2, r2, v2, l2, _ = ref.recurrent_inference(h, action)
+    close(out2.batch_hidden_state, h2)
+    close(out2.batch_reward_scalar, r2)
+    close(out2.batch_policy_logits, l2)
+    net.set_job_rows(0)
+
+
 def _scaled_close(got, want, what):
     """1e-5 relative to the tensor's scale: rtol 1e-5 plus atol 1e-5 x max|want|."""
     want = np.asarray(want)
