@@ -227,7 +227,9 @@ int mz_debug_set_run_mode(mz_net_t* net, int32_t mode);
  * board cell per workgroup up to 768 games, 32 games x one cell up to 2560, 64 games x a group of cells beyond --, 16, 32
  * or 64 force that shape.  The single-cell shapes give bit-identical results; the 64-game shape sums the prediction
  * conv's per-cell terms in a different order: it agrees with them to float rounding (all are held to 1e-5 of the fp64
- * oracle), not bit for bit. */
+ * oracle), not bit for bit.  The initial inference follows the same choice: batches of the 64-game shape take a 64-game
+ * kernel whose 3 -> 128 conv runs on the matrix cores (agreement with the 32-game kernel of the smaller batches: float
+ * rounding, both within 1e-5 of the oracle). */
 int mz_debug_set_job_rows(mz_net_t* net, int32_t rows);
 int mz_debug_run_info(mz_net_t* net, int64_t* out4_host);
 
