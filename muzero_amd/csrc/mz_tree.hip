@@ -418,12 +418,104 @@ __global__ __launch_bounds__(64) void select_action_kernel(PoolDev p, const doub
                                                            int* out_action) {
     if ((int)blockIdx.x < p.T) select_action_tree<MAXA>(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
 }
+// root_stats_tree + select_action_tree of one tree whose action axis fits a wavefront with a lane to spare (A < 64), as one
+// chain of two memory round trips: everything that does not depend on a count is requested first (child k of the root in
+// lane k); the counts reach their action's lane through a forward permute (lanes without a child send theirs to the spare
+// lane 63) instead of a row of zeros that must land before the scatter; the weights' sequential fp64 sums run over
+// v_readlane in lane order -- the arithmetic of select_action_tree, without its LDS staging and barrier.
+__device__ __forceinline__ void root_finish_small(const PoolDev& p, int tree, int lane, int* visits, double* root_value,
+                                                  double* minmax, float* policy, const double* u,
+                                                  const double* temperature, int* out_action) {
+    const int A = p.A;
+    const Slot* slots = f_slots(p, rec(p, tree, 0));
+    const int n = p.n_root[tree];
+    const int rc = p.root_count[tree];
+    int act = 0, cnt = 0;
+    if (lane < A) {                                   // (the record holds A slots; those beyond n are not used below)
+        act = slots[lane].act;
+        cnt = slots[lane].count;
+    }
+    const double t = temperature[tree], uu = u[tree];
+    double vsum = 0.0, mn = 0.0, mx = 0.0;
+    if (lane == 0) {
+        vsum = p.root_vsum[tree];
+        mn = p.mm_min[tree];
+        mx = p.mm_max[tree];
+    }
+    const bool live = lane < n;
+    // mz_root_stats: visits and policy over the full action axis (agent.py:230)
+    const int got = __builtin_amdgcn_ds_permute((live ? act : 63) << 2, live ? (cnt << 1) | 1 : 0);
+    if (lane < A) {
+        const int c = got >> 1;
+        if (visits) visits[(size_t)tree * A + lane] = c;
+        if (policy) policy[(size_t)tree * A + lane] = (got & 1) ? (float)((double)c / (double)rc) : 0.f;
+    }
+    if (lane == 0) {
+        if (root_value) root_value[tree] = rc > 0 ? vsum / (double)rc : std::numeric_limits<double>::quiet_NaN();
+        if (minmax) {
+            minmax[2 * tree] = mn;
+            minmax[2 * tree + 1] = mx;
+        }
+    }
+    // mz_select_action (agent.py:162-168)
+    if (n <= 0) {
+        if (lane == 0) out_action[tree] = -1;
+        return;
+    }
+    if (t == 0.0) {                               // max((count, action)): ties to the largest action
+        long long best = live ? ((long long)cnt << 32) | (unsigned)act : -1;
+        for (int o = 32; o >= 1; o >>= 1) {
+            const long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) out_action[tree] = (int)(best & 0xffffffffll);
+        return;
+    }
+    const double inv_t = 1 / t;
+    const double* tab = nullptr;                  // the host's own pow table of a registered temperature
+#pragma unroll
+    for (int i = 0; i < kPowTables; ++i)
+        if (i < p.n_pow && p.pow_t[i] == t) tab = p.pow_table + (size_t)i * (p.N + 1);
+    double wgt = 0.0;
+    if (live) {
+        if (tab != nullptr) wgt = tab[min(max(cnt, 0), p.N)];
+        else if (inv_t == 1.0) wgt = (double)cnt;       // pow(c, 1.0) == c exactly
+        else if (inv_t == 2.0) wgt = (double)cnt * (double)cnt;
+        else if (inv_t == 4.0) {
+            const double c2 = (double)cnt * (double)cnt;
+            wgt = c2 * c2;
+        } else wgt = pow((double)cnt, inv_t);           // unregistered temperature: the device's pow (not bit-exact)
+    }
+    const int wlo = (int)(__double_as_longlong(wgt) & 0xffffffffll), whi = (int)(__double_as_longlong(wgt) >> 32);
+    auto weight_of = [&](int k) -> double {       // (k is uniform)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(wlo, k), hi = (unsigned)__builtin_amdgcn_readlane(whi, k);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    double total = 0.0;                           // itertools.accumulate: sequential fp64 sums
+    for (int k = 0; k < n; ++k) total = (k == 0) ? weight_of(0) : total + weight_of(k);
+    const double x = uu * (total + 0.0);
+    // bisect_right(cum, x, 0, n-1) == number of cum[i] <= x for i < n-1 (cum is non-decreasing)
+    double cum = 0.0;
+    int idx = 0;
+    for (int k = 0; k < n - 1; ++k) {
+        cum = (k == 0) ? weight_of(0) : cum + weight_of(k);
+        if (!(x < cum)) idx = k + 1;
+        else break;
+    }
+    const int chosen = __builtin_amdgcn_readlane(act, __builtin_amdgcn_readfirstlane(idx));
+    if (lane == 0) out_action[tree] = chosen;
+}
+
 // the end of a move in one launch: mz_root_stats, then mz_select_action
 template <int MAXA>
 __global__ __launch_bounds__(64) void root_finish_kernel(PoolDev p, int* visits, double* root_value, double* minmax,
                                                          float* policy, const double* u, const double* temperature,
                                                          int* out_action) {
     if ((int)blockIdx.x >= p.T) return;
+    if (MAXA == kSmallA && p.A < 64) {
+        root_finish_small(p, blockIdx.x, threadIdx.x, visits, root_value, minmax, policy, u, temperature, out_action);
+        return;
+    }
     root_stats_tree(p, blockIdx.x, threadIdx.x, visits, root_value, minmax, policy);
     select_action_tree<MAXA>(p, blockIdx.x, threadIdx.x, u, temperature, out_action);
 }
