@@ -565,6 +565,59 @@ def test_run_of_simulations_in_chunks(game):
         net.run_simulations_pool(pool, 1, search.hidden, search.reward, search.value, search.logits)
 
 
+@pytest.mark.parametrize('game', ['cartpole', 'tictactoe', 'atari'])
+def test_native_move_ends_like_root_stats_and_select_action(game):
+    """The last launch of a native move (root_finish_kernel: for action axes below 64 one wavefront per tree that scatters
+    the counts with a lane permute and sums the sampling weights over readlane) against mz_root_stats + mz_select_action
+    on the trees the move left in the pool (agent.py:162-168, :229-231): arg-max (t = 0), the exact-product temperatures,
+    registered pow tables (0.7, 3.0), an unregistered temperature, ragged legal lists and finished games."""
+    import torch
+    from muzero_amd.games import atari_shaped, cartpole, tictactoe
+    from muzero_amd.selfplay import LockstepSearch
+    from oracle import net_oracle
+    mod = {'tictactoe': tictactoe, 'cartpole': cartpole, 'atari': atari_shaped}[game]
+    T, N = 140, 20
+    config = mod.make_config(num_simulations=N)
+    net = config.network_config.network_class(config, weights=net_oracle.random_weights(game, 11))
+    A = config.game_config.action_space_size
+    g = torch.Generator(device='cuda').manual_seed(9)
+    if game == 'tictactoe':
+        obs = torch.randint(0, 2, (T, 27), generator=g, device='cuda').float()
+    elif game == 'atari':
+        obs = torch.randn(T, 256, generator=g, device='cuda')
+    else:
+        obs = (torch.rand(T, 4, generator=g, device='cuda') * 2 - 1) * torch.tensor([2.4, 3.0, 0.2, 3.0], device='cuda')
+    noise = torch.distributions.Dirichlet(torch.ones(A, dtype=torch.float64)).sample((T,)).cuda()
+    u = torch.rand(T, generator=g, device='cuda', dtype=torch.float64)
+    temps = [0.0, 0.7, 3.0, 0.5, 0.25, 1.0, 0.9]
+    temp = torch.tensor([temps[i % len(temps)] for i in range(T)], dtype=torch.float64, device='cuda')
+    rng = np.random.default_rng(3)
+    n_legal_h = rng.integers(1, A + 1, size=T).astype(np.int32)
+    n_legal_h[::11] = 0                                                   # finished games
+    legal_h = np.zeros((T, A), np.int32)
+    for t in range(T):                                                    # a random subset, in random order
+        legal_h[t, :n_legal_h[t]] = rng.permutation(A)[:n_legal_h[t]]
+    legal, n_legal = torch.tensor(legal_h, device='cuda'), torch.tensor(n_legal_h, device='cuda')
+    search = LockstepSearch(config, net, num_trees=T)
+    pool = search.pool
+    pool.set_temperature(0.7)
+    pool.set_temperature(3.0)
+    got = [x.clone() for x in search.run_native(obs, noise, u, temp, legal, n_legal)]
+    visits, root_value, minmax, policy = pool.root_stats()
+    chosen = pool.select_action(u, temp)
+    active = n_legal > 0
+    for name, x, y in zip(('visits', 'root_value', 'minmax', 'policy', 'action'), got,
+                          (visits, root_value, minmax, policy, chosen)):
+        assert torch.equal(x[active], y[active]), name
+    assert torch.equal(got[0][~active], torch.zeros_like(got[0][~active]))           # no children: zeros, action -1
+    assert torch.all(got[4][~active] == -1)
+    assert int(got[0][active].sum()) == int(active.sum()) * N
+    # the chosen action is one of the game's legal actions
+    ga = got[4].cpu().numpy()
+    for t in np.nonzero(n_legal_h > 0)[0]:
+        assert ga[t] in legal_h[t, :n_legal_h[t]]
+
+
 @pytest.mark.parametrize('lanes', [2, 3])
 def test_pipelined_lanes_equal_one_lockstep_search(lanes):
     """PipelinedSearch (games split into lanes on separate HIP streams) returns what one LockstepSearch over the same
