@@ -1110,26 +1110,30 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_initial_kernel_w(TttDev w, c
 // Results: sOut[game][0..8] logits, [9] value, [10] reward.  Ends with a barrier.
 // The head's weights as a lane holds them: what ttt_head16 needs that does not depend on any game (ttt_run_kernel asks for
 // them while it waits for the row block's partials).
+// CB = 16-column blocks of the Dense layer per wavefront: 2 in a 256-thread workgroup (four wavefronts), 1 in the 512-thread
+// workgroup of ttt_run_kernel (eight wavefronts: half the fragments to hold, half the MFMAs a wavefront; the same values)
+template <int CB = 2>
 struct HeadW {
-    float4 db[2];                  // Dense bias of this lane's columns
+    float4 db[CB];                 // Dense bias of this lane's columns
     float hb;                      // head bias of output lane % 16
-    float4 bF[2][4][2];            // Dense fragments [column block][k-step][h | l]
+    float4 bF[CB][4][2];           // Dense fragments [column block][k-step][h | l]
     float4 hF[4][2];               // head fragments (wavefront 0)
 };
-__device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW& hw) {
+template <int CB>
+__device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW<CB>& hw) {
     int tid_opaque = threadIdx.x;                    // (opaque to the compiler: see ttt_ring_body)
     asm volatile("" : "+v"(tid_opaque));
-    const int tid = tid_opaque & (kThreads - 1), lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_opaque & (CB == 2 ? kThreads - 1 : kThreadsW - 1), lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g = lane >> 4;
     // biases first: a load issued after the MFMAs would show its whole latency
-    hw.db[0] = *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 4 * g);
-    hw.db[1] = *reinterpret_cast<const float4*>(w.pred_dense_b + wave * 32 + 16 + 4 * g);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) hw.db[c] = *reinterpret_cast<const float4*>(w.pred_dense_b + (CB * wave + c) * 16 + 4 * g);
     hw.hb = w.pred_head_b[n16];
-    const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + wave * 128 + lane;   // column block 2 wave + c
+    const float4* wp = reinterpret_cast<const float4*>(w.pred_dense_p) + wave * (64 * CB) + lane;   // column block CB wave + c
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < CB; ++c) {
             hw.bF[c][s][0] = wp[(2 * s) * 512 + c * 64];
             hw.bF[c][s][1] = wp[(2 * s + 1) * 512 + c * 64];
         }
@@ -1143,22 +1147,24 @@ __device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW& hw) {
     }
 }
 
-template <int NP, bool REWARD, bool COH = false>
+template <int NP, bool REWARD, bool COH = false, int CB = 2>
 __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, const float* __restrict__ ppart,
                                            const float* __restrict__ rpart, float* sXF, float* sHF, float (*sOut)[12],
-                                           const HeadW& hw) {
+                                           const HeadW<CB>& hw) {
     _Float16* sX = reinterpret_cast<_Float16*>(sXF);
     _Float16* sH = reinterpret_cast<_Float16*>(sHF);
     float vmax = 0.f;
-    // in a 512-thread workgroup (ttt_run_kernel) the upper four wavefronts repeat the work of the lower four: the same
-    // values into the same LDS words; every barrier below is then reached by the whole workgroup
+    // CB = 2: four wavefronts (a 512-thread workgroup's upper four would repeat the lower four's work: the same values
+    // into the same LDS words); CB = 1: eight wavefronts, one row of the tile a thread and one column block a wavefront.
+    // Every barrier below is reached by the whole workgroup.
     int tid_opaque = threadIdx.x;                    // (opaque to the compiler: see ttt_ring_body)
     asm volatile("" : "+v"(tid_opaque));
-    const int tid = tid_opaque & (kThreads - 1), lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_opaque & (CB == 2 ? kThreads - 1 : kThreadsW - 1), lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g = lane >> 4;
-    const float4 (&db)[2] = hw.db;
+    constexpr int RT = CB;                           // rows of the tile per thread
+    const float4 (&db)[CB] = hw.db;
     const float hb = hw.hb;
-    const float4 (&bF)[2][4][2] = hw.bF;
+    const float4 (&bF)[CB][4][2] = hw.bF;
     const float4 (&hF)[4][2] = hw.hF;
     // the reward partials too (wave 1): requested now, summed under the first barrier instead of at the very end
     float rp[9];
@@ -1170,16 +1176,16 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
     {   // every load of the tile is issued before the first use
         const int c4 = tid & 31;
         const float4 bn = *reinterpret_cast<const float4*>(w.pred_conv_b + 4 * c4);
-        float4 v[2][NP];
+        float4 v[RT][NP];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             const int b = min(row0 + (tid >> 5) + 8 * i, B - 1);
             const float4* pp = reinterpret_cast<const float4*>(ppart + (size_t)b * 1152) + c4;
 #pragma unroll
             for (int c = 0; c < NP; ++c) v[i][c] = load4<COH>(pp + c * 32);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             float4 t = bn;
             if (NP == 6) {
                 // the 64-game jobs as launches of their own keep the corners' terms in slices of their own (4: cell 2,
@@ -1223,12 +1229,14 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             aF[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
             aF[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
         }
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[CB], acx[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[c] = acx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f16x8 ah = __builtin_bit_cast(f16x8, aF[s][0]), al = __builtin_bit_cast(f16x8, aF[s][1]);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {            // weights as the row operand: acc[c][i] = column 16c + 4g + i, game n16
+            for (int c = 0; c < CB; ++c) {           // weights as the row operand: acc[c][i] = column 16c + 4g + i, game n16
                 const f16x8 bh = __builtin_bit_cast(f16x8, bF[c][s][0]), bl = __builtin_bit_cast(f16x8, bF[c][s][1]);
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[c], 0, 0, 0);
                 acx[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx[c], 0, 0, 0);
@@ -1236,14 +1244,14 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < CB; ++c) {
             const float bb[4] = {db[c].x, db[c].y, db[c].z, db[c].w};
             float x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = fmaxf(acc[c][i] + acx[c][i] * kUnsplit + bb[i], 0.f);
             uint2 h, l;
             split4(x, h, l, vmax);
-            _Float16* row = sH + n16 * kLdH + wave * 32 + 16 * c + 4 * g;
+            _Float16* row = sH + n16 * kLdH + (CB * wave + c) * 16 + 4 * g;
             *reinterpret_cast<uint2*>(row) = h;
             *reinterpret_cast<uint2*>(row + 128) = l;
         }
@@ -1288,7 +1296,7 @@ __global__ __launch_bounds__(kThreads) void ttt_head_kernel(TttDev w, int B, con
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
     const int row0 = blockIdx.x * 16;
-    HeadW hw;
+    HeadW<2> hw;
     ttt_head_weights(w, hw);
     ttt_head16<NP, !INITIAL>(w, B, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
     const int tid = threadIdx.x;
@@ -1315,7 +1323,7 @@ __global__ __launch_bounds__(kThreads) void ttt_head_roots_kernel(TttDev w, Pool
     __shared__ __attribute__((aligned(16))) float sBuf[2][16 * kLd];
     __shared__ float sOut[16][12];
     const int row0 = blockIdx.x * 16, tid = threadIdx.x;
-    HeadW hw;
+    HeadW<2> hw;
     ttt_head_weights(w, hw);
     ttt_head16<4, false>(w, p.T, row0, ppart, nullptr, sBuf[0], sBuf[1], sOut, hw);
     if (tid < 16 * 10) {
@@ -1355,7 +1363,7 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     const bool active = tree < p.T && p.n_root[tree] > 0;
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
     MZ_TRACE_DECL;
-    HeadW hw;
+    HeadW<2> hw;
     ttt_head_weights(w, hw);
     ttt_head16<NP, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
     MZ_TRACE(0);                                                              // head
@@ -1541,7 +1549,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
         MZ_RUN_STAMP(0);
         target += 4;
         meet_arrive(sync.arrive + rb, target, fenced, false, 0, s_flags + 1);
-        HeadW hw;                                    // requested while the arrival is on its way
+        HeadW<1> hw;                                 // requested while the arrival is on its way
         ttt_head_weights(w, hw);
         alive = meet_wait(sync.arrive + rb, target, fenced, s_flags + 1, err_flag);
         MZ_RUN_STAMP(1);
@@ -1567,7 +1575,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void ttt_run_kernel(TttDev w, const P
         const int tree = tx < kThreads ? hrow0 + ht / G : p.T, gl = ht % G;
         const bool active = tree < p.T && p.n_root[tree] > 0;
         const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
-        ttt_head16<4, true, true>(w, p.T, hrow0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
+        ttt_head16<4, true, true, 1>(w, p.T, hrow0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
         const bool store_out = out_stride != 0 || i + 1 == nsim;                  // nobody overwrites these
         if (active && gl < 11 && store_out) {
             const float x = sOut[ht / G][gl];
