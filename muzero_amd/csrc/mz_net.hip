@@ -1345,8 +1345,10 @@ __global__ __launch_bounds__(kThreads) void ttt_head_roots_kernel(TttDev w, Pool
 // logits / value / reward, which go from the head to the tree code through LDS.  One launch boundary less per
 // simulation.  Tree side: 16 lanes per game (A = 9), exactly step_kernel<16, true>'s code (mz_tree_dev.h), so the trees
 // are bit-identical to the separate launches.
+// 512 threads: the head on eight wavefronts (one Dense column block each, ttt_head16's CB = 1), the tree step on the lower
+// four.
 template <bool SELECT, int NP>
-__global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolDev p, int nb, const float* __restrict__ ppart,
+__global__ __launch_bounds__(kThreadsW) void ttt_head_step_kernel(TttDev w, PoolDev p, int nb, const float* __restrict__ ppart,
                                                                  const float* __restrict__ rpart, float* __restrict__ out_reward,
                                                                  float* __restrict__ out_value, float* __restrict__ out_logits,
                                                                  int* out_parent, int* out_action) {
@@ -1359,22 +1361,23 @@ __global__ __launch_bounds__(kThreads) void ttt_head_step_kernel(TttDev w, PoolD
     const int xk = blockIdx.x >> 3;
     const int tid = threadIdx.x,
               row0 = NP == 9 ? blockIdx.x * 16 : (((xk >> 2) * 8 + (blockIdx.x & 7)) * 4 + (xk & 3)) * 16;
-    const int tree = row0 + tid / G, gl = tid % G;
+    const int hgame = (tid & (kThreads - 1)) / G;
+    const int tree = tid < kThreads ? row0 + hgame : p.T, gl = tid % G;
     const bool active = tree < p.T && p.n_root[tree] > 0;
     const BackupPrefetch pf = backprop_prefetch<G>(p, tree, active, gl);      // lands while the head computes
     MZ_TRACE_DECL;
-    HeadW<2> hw;
+    HeadW<1> hw;
     ttt_head_weights(w, hw);
-    ttt_head16<NP, true>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
+    ttt_head16<NP, true, false, 1>(w, p.T, row0, ppart, rpart, sBuf[0], sBuf[1], sOut, hw);
     MZ_TRACE(0);                                                              // head
     if (active && gl < 11) {                                         // the plain outputs of mz_infer_recurrent
-        const float x = sOut[tid / G][gl];
+        const float x = sOut[hgame][gl];
         if (gl < 9) out_logits[(size_t)tree * 9 + gl] = x;
         else if (gl == 9) out_value[tree] = x;
         else out_reward[tree] = x;
     }
     // ---- tree step of these 16 games (agent.py:208-211, then 177-190 for the next simulation)
-    const float* mine = sOut[tid / G];
+    const float* mine = sOut[hgame];
     backprop_tree<G, true>(p, tree, active, gl, nb, mine, mine[10], mine[9], pf);
     if (SELECT) {
         // a tree's 16 lanes lie inside one wavefront, whose vector memory operations are performed in program order:
@@ -4252,18 +4255,18 @@ int mz_infer_recurrent_step(mz_net_t* net, mz_pool_t* pool, int32_t with_select,
     if (ttt_mb(net, batch) != 4) {
         const int grid = (batch + 15) / 16;
         if (with_select)
-            ttt_head_step_kernel<true, 9><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<true, 9><<<grid, kThreadsW, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                      out_reward, out_value, out_logits, parent_block, action);
         else
-            ttt_head_step_kernel<false, 9><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<false, 9><<<grid, kThreadsW, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                       out_reward, out_value, out_logits, parent_block, action);
     } else {
         const int grid = 32 * (((batch + 63) / 64 + 7) / 8);
         if (with_select)
-            ttt_head_step_kernel<true, 6><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<true, 6><<<grid, kThreadsW, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                      out_reward, out_value, out_logits, parent_block, action);
         else
-            ttt_head_step_kernel<false, 6><<<grid, kThreads, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
+            ttt_head_step_kernel<false, 6><<<grid, kThreadsW, 0, st>>>(net->ttt, pool->dev, nb, net->ppart, net->rpart,
                                                                       out_reward, out_value, out_logits, parent_block, action);
     }
     s = launch_status("recurrent inference + tree step");
