@@ -2405,7 +2405,7 @@ __device__ __forceinline__ void cart2_backprop(const PoolDev& q, int lt, bool ac
 
 constexpr int kCartRunMaxDynLds = 120 * 1024;    // beside ~36 KB of static LDS
 
-constexpr int kRunThreads = 256;      // four wavefronts, one per SIMD: 512 registers a lane, 384 of them weights
+constexpr int kRunThreads = 512;      // eight wavefronts, 16 output columns each: 256 registers a lane, 192 of them weights
 __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, PoolDev p, int nb0, int nsim, int final_select,
                                                                     float* hidden_base, int* parent_block, long block_stride,
                                                                     int* action, float* out_reward, float* out_value,
@@ -2453,17 +2453,14 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
     double* sLog = reinterpret_cast<double*>(sTree + L.log);
     double* sXtab = reinterpret_cast<double*>(sTree + L.xtab);
 
-    // the weights, resident for the whole run: six stages x two 16-column blocks x 32 registers
-    BFrag16 wc[2], wd[2], wr[2], w1[2], w2[2], wv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        load_b16(wc[c], w.dyn_conv_s, lane, 2 * wave + c);
-        load_b16(wd[c], w.dyn_dense_s, lane, 2 * wave + c);
-        load_b16(wr[c], w.dyn_rdense_s, lane, 2 * wave + c);
-        load_b16(w1[c], w.pred_dense1_s, lane, 2 * wave + c);
-        load_b16(w2[c], w.pred_dense2_s, lane, 2 * wave + c);
-        load_b16(wv[c], w.pred_value_s, lane, 2 * wave + c);
-    }
+    // the weights, resident for the whole run: six stages x this wavefront's 16-column block x 32 registers
+    BFrag16 wc, wd, wr, w1, w2, wv;
+    load_b16(wc, w.dyn_conv_s, lane, wave);
+    load_b16(wd, w.dyn_dense_s, lane, wave);
+    load_b16(wr, w.dyn_rdense_s, lane, wave);
+    load_b16(w1, w.pred_dense1_s, lane, wave);
+    load_b16(w2, w.pred_dense2_s, lane, wave);
+    load_b16(wv, w.pred_value_s, lane, wave);
     {   // records [0, nb0) of the 16 trees, 16 bytes a thread and step; the records to come start zeroed
         const int per_tree = nrec * 5;
         for (int idx = tid; idx < ROWS * per_tree; idx += kRunThreads) {
@@ -2527,25 +2524,24 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
-        const int lcol0 = wave * 32 + 4 * g;             // this lane's four output columns of game n16 in the wave's first
-                                                         // 16-column block; the second block's are 16 further
+        const int lcol0 = wave * 16 + 4 * g;             // this lane's four output columns of game n16
         // the tree step's lanes: wavefront 0 = 16 DPP quads = the 16 trees (spread over the four wavefronts, four trees
         // each, the step was slower: 104 against 110 M simulations/s)
         const bool tree_lane = wave == 0;
         const int ltree = (lane >> 2) & 15, gl = lane & (G - 1);
         const bool tree_active = tree_lane && row0 + ltree < p.T && q.n_root[ltree] > 0;
-        auto bias4 = [&](int r, int c) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0 + 16 * c); };
+        auto bias4 = [&](int r) { return *reinterpret_cast<const float4*>(sBias + r * 128 + lcol0); };
         auto act4 = [&](const f32x4& acc, const float4& bias, float (&v)[4]) {
             v[0] = fmaxf(acc[0] + bias.x, 0.f);
             v[1] = fmaxf(acc[1] + bias.y, 0.f);
             v[2] = fmaxf(acc[2] + bias.z, 0.f);
             v[3] = fmaxf(acc[3] + bias.w, 0.f);
         };
-        auto store4 = [&](const float (&v)[4], _Float16* sOutT, int c) {
+        auto store4 = [&](const float (&v)[4], _Float16* sOutT) {
             uint2 h, l;
             split4(v, h, l, vmax);
-            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + lcol0 + 16 * c) = h;
-            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + 128 + lcol0 + 16 * c) = l;
+            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + lcol0) = h;
+            *reinterpret_cast<uint2*>(sOutT + n16 * kLdW + 128 + lcol0) = l;
         };
         auto dot4 = [&](const float (&v)[4], const float4& wv) {
             return __builtin_fmaf(v[3], wv.w, __builtin_fmaf(v[2], wv.z, __builtin_fmaf(v[1], wv.y, v[0] * wv.x)));
@@ -2566,12 +2562,11 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         }
         lds_barrier();
         const bool lrow_ok = sRowOff[n16] >= 0;
-        f32x4 acc[2];
+        f32x4 acc;
         float v[4];
         // gather leaf.parent.hidden_state rows (agent.py:204) into LDS: 16 rows x 32 pieces of four floats
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + kRunThreads * j, r = idx >> 5, c4 = idx & 31;
+        {
+            const int idx = tid, r = idx >> 5, c4 = idx & 31;
             const long off = sRowOff[r];
             const float4 x = off >= 0 ? *reinterpret_cast<const float4*>(hidden_base + off + c4 * 4)
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2584,40 +2579,36 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         lds_barrier();
         MZ_TRACE(5);                                     // parent rows gathered
         // Conv1D k=2 valid over [hidden ; action plane] (games/cartpole.py:106): hidden @ W[0] + a * sum_k W[1][k]
-        mma16x2(sH, wc, lane, acc);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        acc = mma16(sH, wc, lane);
+        {
             const float a = sAct[n16];
-            const float4 bc = bias4(0, c), pl = bias4(1, c);
+            const float4 bc = bias4(0), pl = bias4(1);
             const float4 bca = make_float4(bc.x + a * pl.x, bc.y + a * pl.y, bc.z + a * pl.z, bc.w + a * pl.w);
-            act4(acc[c], bca, v);
-            store4(v, sX, c);
+            act4(acc, bca, v);
+            store4(v, sX);
         }
         lds_barrier();
-        mma16x2(sX, wd, lane, acc);                                           // Dense relu = hidden' (:108)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            act4(acc[c], bias4(2, c), v);
-            store4(v, sH, c);                            // sH's previous contents (the gathered input) are no longer read
+        acc = mma16(sX, wd, lane);                                            // Dense relu = hidden' (:108)
+        {
+            act4(acc, bias4(2), v);
+            store4(v, sH);                               // sH's previous contents (the gathered input) are no longer read
             if (lrow_ok)
-                *reinterpret_cast<float4*>(hidden_base + (size_t)nb * block_stride + (size_t)(row0 + n16) * 128 + lcol0 +
-                                           16 * c) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(hidden_base + (size_t)nb * block_stride + (size_t)(row0 + n16) * 128 + lcol0) =
+                    make_float4(v[0], v[1], v[2], v[3]);
         }
         lds_barrier();
         // reward branch: Dense 128 relu, Dense 1 sigmoid (games/cartpole.py:111-114); the dot from the accumulators
-        mma16x2(sH, wr, lane, acc);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            act4(acc[c], bias4(3, c), v);
-            const float part = sum_over_g(dot4(v, bias4(4, c)));
-            if (g == 0) sPart[0][2 * wave + c][n16] = part;
+        acc = mma16(sH, wr, lane);
+        {
+            act4(acc, bias4(3), v);
+            const float part = sum_over_g(dot4(v, bias4(4)));
+            if (g == 0) sPart[0][wave][n16] = part;
         }
         // prediction: Dense relu, Dense relu (games/cartpole.py:121-124)
-        mma16x2(sH, w1, lane, acc);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            act4(acc[c], bias4(5, c), v);
-            store4(v, sX, c);
+        acc = mma16(sH, w1, lane);
+        {
+            act4(acc, bias4(5), v);
+            store4(v, sX);
         }
         lds_barrier();                                     // sX complete, sH no longer read, sPart[0] complete
         MZ_TRACE(6);                                     // four stages
@@ -2629,26 +2620,24 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
             if (keep) out_reward[(size_t)i * out_stride + row0 + tid] = r;
             sOut[tid][0] = r;
         }
-        mma16x2(sX, w2, lane, acc);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            act4(acc[c], bias4(6, c), v);
-            store4(v, sH, c);
+        acc = mma16(sX, w2, lane);
+        {
+            act4(acc, bias4(6), v);
+            store4(v, sH);
             // policy logits: Dense 2 (:127), from the accumulators
-            const float p0 = sum_over_g(dot4(v, bias4(8, c))), p1 = sum_over_g(dot4(v, bias4(9, c)));
+            const float p0 = sum_over_g(dot4(v, bias4(8))), p1 = sum_over_g(dot4(v, bias4(9)));
             if (g == 0) {
-                sPart[1][2 * wave + c][n16] = p0;
-                sPart[2][2 * wave + c][n16] = p1;
+                sPart[1][wave][n16] = p0;
+                sPart[2][wave][n16] = p1;
             }
         }
         lds_barrier();
         // value head: Dense 101 (columns padded to 128) -> softmax -> support_to_scalar (:125, utils.py:146-148)
-        mma16x2(sH, wv, lane, acc);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float4 bv = bias4(7, c);
-            *reinterpret_cast<float4*>(sV + n16 * kLd + lcol0 + 16 * c) =
-                make_float4(acc[c][0] + bv.x, acc[c][1] + bv.y, acc[c][2] + bv.z, acc[c][3] + bv.w);
+        acc = mma16(sH, wv, lane);
+        {
+            const float4 bv = bias4(7);
+            *reinterpret_cast<float4*>(sV + n16 * kLd + lcol0) =
+                make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
         }
         lds_barrier();
         MZ_TRACE(7);                                     // two stages
