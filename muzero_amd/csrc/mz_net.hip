@@ -1871,31 +1871,6 @@ __device__ __forceinline__ f32x4 mma16(const _Float16* sA, const BFrag16& b, int
     }
     return acc + (acx0 + acx1) * kUnsplit;
 }
-// the same for two 16-column blocks of one wave (b[0], b[1]), the activation fragments read once
-__device__ __forceinline__ void mma16x2(const _Float16* sA, const BFrag16 (&b)[2], int lane, f32x4 (&out)[2]) {
-    const _Float16* ap = sA + (lane & 15) * kLdW + 8 * (lane >> 4);
-    float4 a[4][2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[s][0] = *reinterpret_cast<const float4*>(ap + 32 * s);
-        a[s][1] = *reinterpret_cast<const float4*>(ap + 128 + 32 * s);
-    }
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[2] = {z, z}, acx0[2] = {z, z}, acx1[2] = {z, z};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, a[s][0]), al = __builtin_bit_cast(f16x8, a[s][1]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const f16x8 bh = __builtin_bit_cast(f16x8, b[c].v[2 * s]), bl = __builtin_bit_cast(f16x8, b[c].v[2 * s + 1]);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[c], 0, 0, 0);
-            acx0[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acx0[c], 0, 0, 0);
-            acx1[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acx1[c], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) out[c] = acc[c] + (acx0[c] + acx1[c]) * kUnsplit;
-}
 // sum over the four lanes n16 + 16 g of a game (the wave's sixteen columns); every lane gets it
 __device__ __forceinline__ float sum_over_g(float x) {
     const unsigned u = __float_as_uint(x);
@@ -2525,8 +2500,8 @@ __global__ __launch_bounds__(kRunThreads) void cartpole16_run_kernel(CartDev w, 
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
         const int lcol0 = wave * 16 + 4 * g;             // this lane's four output columns of game n16
-        // the tree step's lanes: wavefront 0 = 16 DPP quads = the 16 trees (spread over the four wavefronts, four trees
-        // each, the step was slower: 104 against 110 M simulations/s)
+        // the tree step's lanes: wavefront 0 = 16 DPP quads = the 16 trees (spread over four wavefronts, four trees each,
+        // the step was slower: 104 against 110 M simulations/s, measured on round 2's four-wavefront workgroup)
         const bool tree_lane = wave == 0;
         const int ltree = (lane >> 2) & 15, gl = lane & (G - 1);
         const bool tree_active = tree_lane && row0 + ltree < p.T && q.n_root[ltree] > 0;
