@@ -1119,6 +1119,17 @@ struct HeadW {
     float4 bF[CB][4][2];           // Dense fragments [column block][k-step][h | l]
     float4 hF[4][2];               // head fragments (wavefront 0)
 };
+// wavefront 0's fragments of the ten outputs.  CB = 1 (ttt_run_kernel) asks for them inside ttt_head16, behind the loads
+// of the partials: held across the meeting they cost 32 registers the job loop does not have.
+template <int CB>
+__device__ __forceinline__ void ttt_head_weights_out(const TttDev& w, HeadW<CB>& hw, int lane) {
+    const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + lane;                 // column block 0
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        hw.hF[s][0] = hp[(2 * s) * 512];
+        hw.hF[s][1] = hp[(2 * s + 1) * 512];
+    }
+}
 template <int CB>
 __device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW<CB>& hw) {
     int tid_opaque = threadIdx.x;                    // (opaque to the compiler: see ttt_ring_body)
@@ -1137,14 +1148,7 @@ __device__ __forceinline__ void ttt_head_weights(const TttDev& w, HeadW<CB>& hw)
             hw.bF[c][s][0] = wp[(2 * s) * 512 + c * 64];
             hw.bF[c][s][1] = wp[(2 * s + 1) * 512 + c * 64];
         }
-    if (wave == 0) {
-        const float4* hp = reinterpret_cast<const float4*>(w.pred_head_p) + lane;                 // column block 0
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            hw.hF[s][0] = hp[(2 * s) * 512];
-            hw.hF[s][1] = hp[(2 * s + 1) * 512];
-        }
-    }
+    if (CB == 2 && wave == 0) ttt_head_weights_out(w, hw, lane);
 }
 
 template <int NP, bool REWARD, bool COH = false, int CB = 2>
@@ -1165,7 +1169,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
     const float4 (&db)[CB] = hw.db;
     const float hb = hw.hb;
     const float4 (&bF)[CB][4][2] = hw.bF;
-    const float4 (&hF)[4][2] = hw.hF;
+    HeadW<CB> hw_out;                                // CB = 1: the output fragments, requested below
     // the reward partials too (wave 1): requested now, summed under the first barrier instead of at the very end
     float rp[9];
     if (REWARD && wave == 1 && lane < 16) {
@@ -1184,6 +1188,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
 #pragma unroll
             for (int c = 0; c < NP; ++c) v[i][c] = load4<COH>(pp + c * 32);
         }
+        if (CB == 1 && wave == 0) ttt_head_weights_out(w, hw_out, lane);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             float4 t = bn;
@@ -1269,6 +1274,7 @@ __device__ __forceinline__ void ttt_head16(const TttDev& w, int B, int row0, con
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                // games as the row operand: acc[i] = game 4g + i, output n16
             const f16x8 ah = __builtin_bit_cast(f16x8, aF[s][0]), al = __builtin_bit_cast(f16x8, aF[s][1]);
+            const float4 (&hF)[4][2] = CB == 1 ? hw_out.hF : hw.hF;
             const f16x8 bh = __builtin_bit_cast(f16x8, hF[s][0]), bl = __builtin_bit_cast(f16x8, hF[s][1]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
             acx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx0, 0, 0, 0);
