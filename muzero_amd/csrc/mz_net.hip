@@ -2863,10 +2863,7 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
     const int tree = FUSE ? row0 + tid / TG : 0, tgl = tid % TG;
     bool tree_active = false;
     BackupPrefetchT<TPB> pf;
-    if (FUSE) {
-        tree_active = tree < p.T && p.n_root[tree] > 0;
-        pf = backprop_prefetch<TG, TPB>(p, tree, tree < p.T, tgl);            // lands while the network computes
-    }
+    if (FUSE) tree_active = tree < p.T && p.n_root[tree] > 0;
     BFragW bw;
     load_bw(bw, INITIAL ? w.ini_s : w.rec_s, lane, wave);
     float vmax = 0.f;                                // largest magnitude split by this lane (note_range)
@@ -3022,6 +3019,9 @@ __device__ __forceinline__ void atari_body(const AtariDev& w, int B, const float
         }
     }
     MZ_TRACE_NW(4);                                  // hidden state out, reward partials
+    // the backup's inputs: requested here, where the residual registers have just died, not at the start (32 registers held
+    // across the dynamics stages); they land during the prediction's three stages and heads
+    if (FUSE) pf = backprop_prefetch<TG, TPB>(p, tree, tree < p.T, tgl);
     // prediction: Conv1D k=2 valid over the two positions, relu -> P
     {
         const float4 bq = *reinterpret_cast<const float4*>(w.pred_conv_b + lcol);
