@@ -328,35 +328,39 @@ def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic_<workload>.json:
     FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be
     read from inside this process, so the figure is the one of the latest committed profile; None when there is none."""
+    for path in profile_files('hbm_traffic', workload):
+        with open(path) as f:
+            data = json.load(f)
+        rows = [row for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
+        if rows:
+            row = max(rows, key=lambda r: r['launches'])  # e.g. step_kernel<G, P, true> among its instantiations
+            return row['traffic_bytes_per_launch'], os.path.basename(path)
+    return None, None
+
+
+def profile_files(what, workload):
+    """The committed profiles of a workload, latest round first: profiles/rNN_<what>_<workload>.json and, for the
+    workloads that are also profiled with their network in the loop beside the injected tree-only run, ..._net.json."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*_hbm_traffic_{workload}.json')))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        data = json.load(f)
-    rows = [row for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
-    if not rows:
-        return None, None
-    row = max(rows, key=lambda r: r['launches'])          # e.g. step_kernel<G, P, true> among its instantiations
-    return row['traffic_bytes_per_launch'], os.path.basename(files[-1])
+    files = glob.glob(os.path.join(ROOT, 'profiles', f'*_{what}_{workload}.json'))
+    files += glob.glob(os.path.join(ROOT, 'profiles', f'*_{what}_{workload}_net.json'))
+    return sorted(files, key=os.path.basename, reverse=True)
 
 
 def profiled_stats(workload, kernel):
     """Duration statistics of `kernel` from the committed rocprofv3 kernel trace of this workload
     (profiles/*_kernel_medians_<workload>.json, made by tools/profile_workload.sh from `rocprofv3 --kernel-trace`), with the
     ms_per_step the profiled run itself printed: the figures the live HIP-event average should agree with."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*_kernel_medians_{workload}.json')))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        data = json.load(f)
-    rows = [dict(row, name=name) for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
-    if not rows:
-        return None
-    row = max(rows, key=lambda r: r['calls'])
-    return {'kernel': row['name'], 'median_us': row['median_us'], 'mean_us': row['mean_us'], 'min_us': row['min_us'],
-            'calls': row['calls'], 'ms_per_step_under_rocprof': data.get('ms_per_step'), 'source': os.path.basename(files[-1])}
+    for path in profile_files('kernel_medians', workload):
+        with open(path) as f:
+            data = json.load(f)
+        rows = [dict(row, name=name) for name, row in data.get('kernels', {}).items() if name.startswith(kernel)]
+        if rows:
+            row = max(rows, key=lambda r: r['calls'])
+            return {'kernel': row['name'], 'median_us': row['median_us'], 'mean_us': row['mean_us'],
+                    'min_us': row['min_us'], 'calls': row['calls'], 'ms_per_step_under_rocprof': data.get('ms_per_step'),
+                    'source': os.path.basename(path)}
+    return None
 
 
 def host_cores():
