@@ -480,8 +480,12 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
         const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4, lcol = wave * 16 + 4 * g;
         const int kind = Dc.x & 0xff, cell = Dc.y;
         const bool has_next = d + 1 < d1;
-        const Desc Dn3 = desc[d + 3 < d1 ? d + 3 : 0];          // used from the next iteration on: a scalar load with the
-                                                                // whole stage to arrive in
+        // the descriptor three stages ahead: requested under the LAST k-step's MFMAs (below).  Requested here it was in
+        // flight at the stage's first LDS wait, and a wait with scalar loads outstanding can only be for everything
+        // (lgkmcnt counts both, scalar loads return out of order): the first MFMAs then waited for the fragment reads of the
+        // SECOND k-step, issued just before them, instead of for their own only.  (Taken from a per-lane table by
+        // v_readlane -- no memory operation at all -- the stage loop was slower: 92.9 against 94.2 M simulations/s.)
+        Desc Dn3;
         // next stage's weights (a redundant reload of this stage's on the last stage keeps the loop branch-free)
         const float4* wnext = wlane + (size_t)(has_next ? Dn.z : Dc.z) * 4096;
         // af[0] holds this stage's first fragments already: requested under the previous stage's last MFMAs (a gathered
@@ -548,6 +552,7 @@ __device__ __forceinline__ bool ttt_ring_body(const TttDev& w, int B, const floa
                         af[0][m][1] = *reinterpret_cast<const float4*>(np + m * 16 * kLdW + 128);
                     }
                 }
+                if (s == 3) Dn3 = desc[d + 3 < d1 ? d + 3 : 0];
                 const f16x8 bh = __builtin_bit_cast(f16x8, bw.v[2 * s]), bl = __builtin_bit_cast(f16x8, bw.v[2 * s + 1]);
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
