@@ -563,22 +563,65 @@ struct TreeLds {
 // NumPy float32 pairwise summation (trap T4) over a row a[0..A) staged in LDS by one group: eight lanes (an octet)
 // per leaf, G/8 leaves at a time, the 8-accumulator combine by DPP; groups narrower than an octet leave it to
 // their lane 0.  Returns the sum in every lane of the group.
+// The sum program of a wide action axis as one lane needs it, requested BEFORE the row it will sum is staged: the leaf
+// this lane's octet takes in the first pass and the first merges.  Read inside numpy_sum_lds they were dependent global
+// round trips in the middle of the expansion (Go shape: four leaves, three merges -- a third of the expansion's time).
+constexpr int kSumProgMerges = 4;
+struct SumProg {
+    bool ok;                       // the program was requested (more than one leaf)
+    int lo, n;                     // leaf `octet` (0, 0 beyond the last)
+    int dst[kSumProgMerges], src[kSumProgMerges];
+};
 template <int G>
-__device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int gl) {
+__device__ __forceinline__ SumProg sum_prog_load(const PoolDev& p, int gl) {
+    SumProg sp;
+    sp.ok = G >= 8 && p.n_sum_leaf > 1;
+    sp.lo = sp.n = 0;
+#pragma unroll
+    for (int m = 0; m < kSumProgMerges; ++m) sp.dst[m] = sp.src[m] = 0;
+    if (sp.ok) {
+        const int s = gl >> 3;
+        if (s < p.n_sum_leaf) {
+            sp.lo = p.sum_leaf[2 * s];
+            sp.n = p.sum_leaf[2 * s + 1];
+        }
+#pragma unroll
+        for (int m = 0; m < kSumProgMerges; ++m)
+            if (m < p.n_sum_merge) {
+                sp.dst[m] = p.sum_merge[2 * m];
+                sp.src[m] = p.sum_merge[2 * m + 1];
+            }
+    }
+    return sp;
+}
+
+template <int G>
+__device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a, float* scratch, int gl,
+                                               const SumProg* sp = nullptr) {
     // n <= 128: the recursion is the single leaf (0, A) -- known without the dependent global reads of the program
     const bool one_leaf = p.n_sum_leaf == 1;
+    const bool pre = sp != nullptr && sp->ok;
     if (G >= 8) {
         constexpr int OCT = G >= 8 ? G / 8 : 1;
         const int oct = gl >> 3, i = gl & 7;
         for (int s0 = 0; s0 < p.n_sum_leaf; s0 += OCT) {
             const int s = s0 + oct;
             const bool has = s < p.n_sum_leaf;
-            const int lo = has && !one_leaf ? p.sum_leaf[2 * s] : 0, n = !has ? 0 : one_leaf ? p.A : p.sum_leaf[2 * s + 1];
+            const bool first = pre && s0 == 0;                   // this pass's leaves came with the prefetch
+            const int lo = first ? sp->lo : has && !one_leaf ? p.sum_leaf[2 * s] : 0,
+                      n = first ? sp->n : !has ? 0 : one_leaf ? p.A : p.sum_leaf[2 * s + 1];
             const int nfull = n - (n % 8);
             float r = 0.f;
             if (nfull >= 8) {
-                r = a[lo + i];
-                for (int m = 8; m < nfull; m += 8) r += a[lo + m + i];
+                // a leaf has at most 128 elements (NumPy's block size): this lane's up to sixteen are all requested before
+                // the first is added (the loop of dependent LDS reads was a sixteen-deep latency chain), then added in order
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = a[lo + min(8 * j, nfull - 8) + i];
+                r = v[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j)
+                    if (8 * j < nfull) r += v[j];
             }
             r += dpp_f32<kDppXor1>(r);             // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): fp32 + is commutative,
             r += dpp_f32<kDppXor2>(r);             // so every lane of the octet ends with lane 0's bits
@@ -610,7 +653,20 @@ __device__ __forceinline__ float numpy_sum_lds(const PoolDev& p, const float* a,
     }
     if (gl == 0) {
         for (int m = 0; m < p.n_sum_merge; ++m) {
-            const int dst = p.sum_merge[2 * m], src = p.sum_merge[2 * m + 1];
+            int dst, src;
+            if (pre && m < kSumProgMerges) {
+                dst = sp->dst[0];
+                src = sp->src[0];
+#pragma unroll
+                for (int j = 1; j < kSumProgMerges; ++j)
+                    if (m == j) {
+                        dst = sp->dst[j];
+                        src = sp->src[j];
+                    }
+            } else {
+                dst = p.sum_merge[2 * m];
+                src = p.sum_merge[2 * m + 1];
+            }
             scratch[dst] = scratch[dst] + scratch[src];
         }
     }
@@ -811,10 +867,14 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         if (active && gl < A) store_new_slot(f_slots(p, rec(p, tree, nb)) + slot, pr, gl);
     } else if (lds_row != nullptr && A <= L::kMaxA) {
         // priors staged in the group's LDS row (softmax terms summed there in NumPy's order)
+        constexpr bool kWide = L::kMaxA > 128;               // rows that can take more than one leaf of the sum
+        SumProg sp;
+        sp.ok = false;
+        if (LOGITS && kWide) sp = sum_prog_load<G>(p, gl);
         for (int k = gl; k < A; k += G) lds_row[k] = !active ? 0.f : LOGITS ? expf(pol_row[k]) : pol_row[k];
         __builtin_amdgcn_wave_barrier();
         if (LOGITS) {
-            const float total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl);
+            const float total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl, kWide ? &sp : nullptr);
             for (int k = gl; k < A; k += G) lds_row[k] = lds_row[k] / total;          // network.py:146
             __builtin_amdgcn_wave_barrier();
         }
