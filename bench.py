@@ -435,11 +435,17 @@ def timed_region(move, steps, warmup, world, with_net, event_every=10, sync_ever
     GPU's clocks are still on their way up from idle) -- the figure of interest is the second, and it is what a
     timed region of any length reports once the chip has been busy for a few hundred milliseconds."""
     import torch.distributed as dist
-    t_pre = time.perf_counter()
+    # The pre-warm is bounded by time, so the ranks of an N > 1 run make different numbers of moves in it: it must hold no
+    # collective (the ranks' collectives pair up by order), and runs with the per-move all-gather switched off.
+    gather, t_pre = getattr(move, 'gather', None), time.perf_counter()
+    if gather is not None:
+        move.gather = None
     while prewarm_s > 0 and time.perf_counter() - t_pre < prewarm_s:
         for _ in range(8):
             move.run(timed_events=False)
         torch.cuda.synchronize()
+    if gather is not None:
+        move.gather = gather
     for i in range(warmup):
         move.run(timed_events=(i == 0))              # the first warm-up step also warms the event-recording path
     if with_net:
@@ -546,6 +552,9 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help="weak: the workload's games PER GPU (default); strong: the workload's games in total, sharded "
                          "over the ranks (BASELINE.json configs[2] read as 4096 games over 1/2/4/8 GPUs)")
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl (= RCCL, one rank per GPU: what the driver runs); gloo rehearses the N > 1 line on a box with '
+                         'fewer GPUs than ranks (ranks share GPUs, the collectives go through the host: not a measurement)')
     ap.add_argument('--lanes', type=int, default=1,
                     help='split the games of a GPU into this many lockstep lanes on separate HIP streams')
     ap.add_argument('--event-every', type=int, default=10,
@@ -554,6 +563,9 @@ def main():
                     help='... and there on every S-th simulation only')
     args = ap.parse_args()
 
+    if os.environ.get('MZ_BENCH_WATCHDOG'):          # rehearsals: where every thread stands after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['MZ_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -574,8 +586,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group('gloo')
     else:
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
@@ -708,6 +724,8 @@ def main():
                        'ranks_in_all_reduce': ranks_seen},
             'roofline': roofline,
         }
+        if world > 1 and args.dist_backend != 'nccl':
+            out['rehearsal'] = f'{args.dist_backend} backend, ranks share GPUs: a test of the N > 1 line, not a measurement'
         if default_line:
             out['roofline']['rocprof'] = profiled_stats(args.workload, roofline['kernel'])
         out.update(extra)
