@@ -871,6 +871,36 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
         SumProg sp;
         sp.ok = false;
         if (LOGITS && kWide) sp = sum_prog_load<G>(p, gl);
+        constexpr int kHeld = 8;                             // softmax terms a lane keeps in registers
+        if (!p.sort_nodes && A <= kHeld * G) {
+            // a pool that does not rank its nodes (wide action axes): nothing to check and nothing to hand to other lanes, a
+            // lane's priors go from its softmax terms straight into its slots -- the terms stay in registers (the row is
+            // staged for the sum only), all requested before the first exponential
+            float x[kHeld];
+#pragma unroll
+            for (int j = 0; j < kHeld; ++j) {
+                const int k = gl + G * j;
+                x[j] = k < A ? pol_row[k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kHeld; ++j) {
+                const int k = gl + G * j;
+                if (k < A) {
+                    x[j] = !active ? 0.f : LOGITS ? expf(x[j]) : x[j];
+                    if (LOGITS) lds_row[k] = x[j];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float total = 1.f;
+            if (LOGITS) total = numpy_sum_lds<G>(p, lds_row, lds_row + L::kMaxA, gl, kWide ? &sp : nullptr);
+            Slot* slots = f_slots(p, rec(p, active ? tree : 0, active ? nb : 0));
+#pragma unroll
+            for (int j = 0; j < kHeld; ++j) {
+                const int k = gl + G * j;
+                if (active && k < A) store_new_slot(slots + k, LOGITS ? x[j] / total : x[j], k);     // network.py:146
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
         for (int k = gl; k < A; k += G) lds_row[k] = !active ? 0.f : LOGITS ? expf(pol_row[k]) : pol_row[k];
         __builtin_amdgcn_wave_barrier();
         if (LOGITS) {
@@ -890,6 +920,7 @@ __device__ void backprop_tree(const PoolDev& p, int tree, bool active, int gl, i
             if (active) store_new_slot(slots + slot, pr, k);
         }
         __builtin_amdgcn_wave_barrier();
+        }
     } else {
         // no LDS row, or an action axis wider than it: unsorted slots; softmax terms staged in the new record's
         // backup half (unused until the first backup through a slot) and summed through global memory
