@@ -518,7 +518,12 @@ def tree_roofline_leg(name, device, steps, seed):
     mean_d = sum_d / sims
     out = tree_roofline(move, wl, name, mean_d, cost)
     out.update({'workload': name, 'trees': wl['T'], 'actions': wl['A'], 'simulations_per_move': wl['N'], 'steps': steps,
-                'simulations_per_sec': sims / elapsed, 'ms_per_move': elapsed / steps * 1e3})
+                'simulations_per_sec': sims / elapsed, 'ms_per_move': elapsed / steps * 1e3,
+                # the first step of a leg is a launch per simulation with events (the launch_per_simulation figures), so the
+                # leg's own rate is below that of the one-launch run it reports beside it:
+                'one_launch_simulations_per_sec': wl['T'] * wl['N'] / (out['avg_launch_us'] * 1e-6),
+                'note': 'simulations_per_sec is over all steps of the leg, one of which is a launch per simulation with '
+                        'events; one_launch_simulations_per_sec = trees x simulations / avg_launch_us'})
     for l in move.lanes:
         l['pool'].close()
     del move
